@@ -1,0 +1,118 @@
+"""Build libpropainter_mi355.so (gfx950) in-tree with hipcc.
+
+`python -m comfyui_propainter_nodes_amd.build` compiles every `csrc/*.hip` translation unit
+for gfx950 and links `comfyui_propainter_nodes_amd/libpropainter_mi355.so`.  hipcc cross-compiles without a
+GPU, so this also runs in the build container.  `--emu` additionally builds the
+test-only x86 emulation of the same sources (tests/emu/libpropainter_emu.so); the product
+never loads that library.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libpropainter_mi355.so"
+EMU_DIR = ROOT / "tests" / "emu"
+EMU_LIB = EMU_DIR / "libpropainter_emu.so"
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HOST_CLANG = os.environ.get("PP_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
+
+
+def _sources() -> list[Path]:
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _headers() -> list[Path]:
+    return sorted(CSRC.glob("*.h")) + sorted((ROOT / "include").glob("*.h"))
+
+
+def _digest(paths: list[Path], extra: str) -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"build failed: {cmd[0]}")
+
+
+def _compile_all(objs_dir: Path, compile_one, link, out: Path, stamp_extra: str, force: bool) -> Path:
+    srcs = _sources()
+    hdrs = _headers()
+    objs_dir.mkdir(parents=True, exist_ok=True)
+    hdr_digest = _digest(hdrs, stamp_extra)
+    objs = []
+    jobs = []
+    for s in srcs:
+        o = objs_dir / (s.stem + ".o")
+        stamp = objs_dir / (s.stem + ".stamp")
+        want = _digest([s], hdr_digest)
+        objs.append(o)
+        if force or not o.exists() or not stamp.exists() or stamp.read_text() != want:
+            jobs.append((s, o, stamp, want))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(lambda j: compile_one(j[0], j[1]), jobs))
+        for _, _, stamp, want in jobs:
+            stamp.write_text(want)
+    if jobs or not out.exists():
+        link(objs, out)
+    return out
+
+
+def build_hip(force: bool = False) -> Path:
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+             "-I", str(CSRC), "-I", str(ROOT / "include")]
+
+    def compile_one(src: Path, obj: Path) -> None:
+        _run([HIPCC, *flags, "-c", str(src), "-o", str(obj)])
+
+    def link(objs: list[Path], out: Path) -> None:
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(out)])
+
+    return _compile_all(PKG / "build" / "hip", compile_one, link, LIB, "hip" + " ".join(flags), force)
+
+
+def build_emu(force: bool = False) -> Path:
+    """TEST ONLY: the same kernel sources compiled for x86 against tests/emu/pp_emu.h."""
+    flags = ["-O2", "-std=c++17", "-fPIC", "-DPP_EMU", "-x", "c++", "-Wno-unused-value",
+             "-I", str(CSRC), "-I", str(ROOT / "include"), "-I", str(EMU_DIR)]
+
+    def compile_one(src: Path, obj: Path) -> None:
+        _run([HOST_CLANG, *flags, "-c", str(src), "-o", str(obj)])
+
+    def link(objs: list[Path], out: Path) -> None:
+        rt = EMU_DIR / "build" / "pp_emu_rt.o"
+        _run([HOST_CLANG, "-O2", "-std=c++17", "-fPIC", "-I", str(EMU_DIR), "-c",
+              str(EMU_DIR / "pp_emu.cpp"), "-o", str(rt)])
+        _run([HOST_CLANG, "-shared", "-fPIC", *map(str, objs), str(rt), "-lpthread", "-o", str(out)])
+
+    extra = "emu" + " ".join(flags) + (EMU_DIR / "pp_emu.h").read_text() + (EMU_DIR / "pp_emu.cpp").read_text()
+    return _compile_all(EMU_DIR / "build", compile_one, link, EMU_LIB, extra, force)
+
+
+def main(argv: list[str]) -> int:
+    force = "--force" in argv
+    out = build_hip(force)
+    print(f"built {out}")
+    if "--emu" in argv:
+        out = build_emu(force)
+        print(f"built {out}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main(sys.argv[1:]))

@@ -1,0 +1,398 @@
+// conv_igemm.hip -- implicit-GEMM convolution for gfx950 MFMA (see include/propainter_mi355.h).
+//
+// Formulation:  D[cout][pixel] = sum_k Wp[cout][k] * X[pixel][k],   k = (tap, segment, channel)
+// The weight tile is the MFMA A operand (rows = output channels), the gathered
+// channels-last pixel tile is the B operand (cols = output pixels).  With the 16x16 C/D
+// map (lane -> col = l&15, rows 4*(l>>4)+r) every lane ends up with 4 *consecutive output
+// channels of one pixel*, i.e. one 8-byte (f16) / 16-byte (f32) channels-last store.
+//
+// Work-group = 256 threads = 4 waves arranged WC x WP; each wave owns (TC*16) x (TP*16).
+// K is walked in chunks of 32 channels of one (tap, segment); both tiles are staged
+// global -> VGPR -> LDS (rows padded by one 16-byte access to break the power-of-two
+// pitch), double-buffered, one barrier per chunk.
+//
+//   f16 : v_mfma_f32_16x16x32_f16, one MFMA per (tc,tp) per chunk.
+//   f32 : v_mfma_f32_16x16x4_f32 (exact f32).  A lane reads a float4 = k 4g..4g+3 of a
+//         16-wide sub-chunk and feeds element j to MFMA step j; lane group g therefore
+//         supplies k = 4g + j at step j for BOTH operands, which only permutes the
+//         summation order.
+#include "pp_device.h"
+#include "pp_host.h"
+
+namespace pp {
+
+struct ConvK {
+  const void* in_ptr[PP_MAX_SEG];
+  int in_C[PP_MAX_SEG];
+  int in_ldc[PP_MAX_SEG];
+  int64_t in_zoff[PP_MAX_SEG];
+  int seg_chunks[PP_MAX_SEG];
+  int nseg;
+  int N, H, W, Ho, Wo;
+  int kh, kw, sh, sw, ph, pw, dh, dw;
+  int pad_mode;
+  const void* weight;
+  int64_t w_zoff;
+  int Kp;
+  const float* bias;
+  int64_t bias_zoff;
+  int Cout;
+  int64_t M;
+  void* out;
+  int out_ldc;
+  int64_t out_zoff;
+  int act, act2, act_split;
+  float act_param, out_scale;
+  int epi;
+  const void* aux1;
+  int aux1_ldc;
+  int64_t aux1_zoff;
+  const void* aux2;
+  int aux2_ldc;
+  int64_t aux2_zoff;
+  int chunks_per_tap;
+  int nchunks;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float param) {
+  switch (act) {
+    case PP_ACT_RELU: return v > 0.f ? v : 0.f;
+    case PP_ACT_LEAKY: return v > 0.f ? v : v * param;
+    case PP_ACT_SIGMOID: return sigmoidf_(v);
+    case PP_ACT_TANH: return tanhf(v);
+    case PP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    default: return v;
+  }
+}
+
+template <typename T>
+struct Frag;
+template <>
+struct Frag<half_t> {
+  typedef h8 piece;  // 16 bytes
+};
+template <>
+struct Frag<float> {
+  typedef f4 piece;
+};
+
+template <typename T, typename OT, int WC, int WP, int TC, int TP>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
+  constexpr int BK = 32;
+  constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
+  constexpr int PPR = BK / EPP;             // pieces per tile row (4 f16, 8 f32)
+  constexpr int LDK = BK + EPP;             // padded LDS row pitch in elements
+  constexpr int BC = WC * TC * 16;
+  constexpr int BP = WP * TP * 16;
+  constexpr int RPP = 256 / PPR;  // rows filled per pass
+  constexpr int XPASS = (BP + RPP - 1) / RPP;
+  constexpr int WPASS = (BC + RPP - 1) / RPP;
+  typedef typename Frag<T>::piece piece_t;
+
+  T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);
+  T* Xs = smem;                     // [2][BP][LDK]
+  T* Ws = smem + 2 * BP * LDK;      // [2][BC][LDK]
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wc = wave / WP;
+  const int wp = wave % WP;
+  const int z = (int)blockIdx.z;
+  const int64_t p_base = (int64_t)blockIdx.x * BP;
+  const int c_base = (int)blockIdx.y * BC;
+
+  const int pc = tid % PPR;   // piece column inside a tile row
+  const int row0 = tid / PPR;
+
+  // ---- per-thread pixel rows of the X tile --------------------------------------------
+  int py0[XPASS], px0[XPASS];
+  int64_t pn[XPASS];
+  bool pvalid[XPASS];
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) {
+    const int r = row0 + i * RPP;
+    const int64_t m = p_base + r;
+    const bool ok = (r < BP) && (m < p.M);
+    pvalid[i] = ok;
+    const int64_t mm = ok ? m : 0;
+    const int wo = (int)(mm % p.Wo);
+    const int64_t t = mm / p.Wo;
+    const int ho = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    py0[i] = ho * p.sh - p.ph;
+    px0[i] = wo * p.sw - p.pw;
+    pn[i] = (int64_t)n * p.H * p.W;
+  }
+  // ---- per-thread weight rows -----------------------------------------------------------
+  const T* wbase = reinterpret_cast<const T*>(p.weight) + (int64_t)z * p.w_zoff;
+
+  piece_t xreg[XPASS];
+  piece_t wreg[WPASS];
+
+  auto load_chunk = [&](int q) {
+    const int tap = q / p.chunks_per_tap;
+    int rem = q - tap * p.chunks_per_tap;
+    int seg = 0;
+#pragma unroll
+    for (int s = 0; s < PP_MAX_SEG - 1; ++s) {
+      if (seg == s && s + 1 < p.nseg && rem >= p.seg_chunks[s]) {
+        rem -= p.seg_chunks[s];
+        seg = s + 1;
+      }
+    }
+    const int ky = tap / p.kw;
+    const int kx = tap - ky * p.kw;
+    const int c0 = rem * BK + pc * EPP;
+    const bool cvalid = c0 < p.in_C[seg];
+    const T* sbase = reinterpret_cast<const T*>(p.in_ptr[seg]) + (int64_t)z * p.in_zoff[seg];
+    const int ldc = p.in_ldc[seg];
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      int y = py0[i] + ky * p.dh;
+      int x = px0[i] + kx * p.dw;
+      bool ok = pvalid[i] && cvalid;
+      if (p.pad_mode == PP_PAD_REPLICATE) {
+        y = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
+        x = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
+      } else {
+        ok = ok && (y >= 0) && (y < p.H) && (x >= 0) && (x < p.W);
+      }
+      piece_t v;
+#pragma unroll
+      for (int e = 0; e < EPP; ++e) v[e] = (T)0;
+      if (ok) {
+        const T* src = sbase + (pn[i] + (int64_t)y * p.W + x) * ldc + c0;
+        v = *reinterpret_cast<const piece_t*>(src);
+      }
+      xreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i) {
+      const int r = row0 + i * RPP;
+      const int co = c_base + r;
+      piece_t v;
+#pragma unroll
+      for (int e = 0; e < EPP; ++e) v[e] = (T)0;
+      if (r < BC && co < p.Cout) {
+        const T* src = wbase + (int64_t)co * p.Kp + (int64_t)q * BK + pc * EPP;
+        v = *reinterpret_cast<const piece_t*>(src);
+      }
+      wreg[i] = v;
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    T* xs = Xs + buf * BP * LDK;
+    T* ws = Ws + buf * BC * LDK;
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      const int r = row0 + i * RPP;
+      if (r < BP) *reinterpret_cast<piece_t*>(xs + r * LDK + pc * EPP) = xreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i) {
+      const int r = row0 + i * RPP;
+      if (r < BC) *reinterpret_cast<piece_t*>(ws + r * LDK + pc * EPP) = wreg[i];
+    }
+  };
+
+  f4 acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fgrp = lane >> 4;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int q = 0; q < p.nchunks; ++q) {
+    const int buf = q & 1;
+    if (q + 1 < p.nchunks) load_chunk(q + 1);
+
+    const T* xs = Xs + buf * BP * LDK + (wp * TP * 16 + frow) * LDK;
+    const T* ws = Ws + buf * BC * LDK + (wc * TC * 16 + frow) * LDK;
+    if constexpr (sizeof(T) == 2) {
+      h8 af[TC], bf[TP];
+#pragma unroll
+      for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(ws + a * 16 * LDK + fgrp * 8);
+#pragma unroll
+      for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const h8*>(xs + b * 16 * LDK + fgrp * 8);
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(af[a], bf[b], acc[a][b]);
+    } else {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        f4 af[TC], bf[TP];
+#pragma unroll
+        for (int a = 0; a < TC; ++a)
+          af[a] = *reinterpret_cast<const f4*>(ws + a * 16 * LDK + sub * 16 + fgrp * 4);
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+          bf[b] = *reinterpret_cast<const f4*>(xs + b * 16 * LDK + sub * 16 + fgrp * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int a = 0; a < TC; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x4_f32(af[a][j], bf[b][j], acc[a][b]);
+      }
+    }
+
+    if (q + 1 < p.nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------
+  const float* bias = p.bias ? p.bias + (int64_t)z * p.bias_zoff : nullptr;
+  OT* out = reinterpret_cast<OT*>(p.out) + (int64_t)z * p.out_zoff;
+  const OT* aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
+  const OT* aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
+#pragma unroll
+  for (int b = 0; b < TP; ++b) {
+    const int64_t m = p_base + wp * TP * 16 + b * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int a = 0; a < TC; ++a) {
+      const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
+      if (c >= p.Cout) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = c + r;
+        float t = acc[a][b][r];
+        if (bias && cc < p.Cout) t += bias[cc];
+        if (p.act_split > 0 && cc >= p.act_split) {
+          t = apply_act(t, p.act2, p.act_param);
+        } else {
+          t = apply_act(t, p.act, p.act_param);
+          if (p.out_scale != 0.f) t *= p.out_scale;
+        }
+        v[r] = t;
+      }
+      if (p.epi != PP_EPI_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = c + r;
+          if (cc >= p.Cout) continue;
+          const float a1 = to_f32(aux1[m * p.aux1_ldc + cc]);
+          if (p.epi == PP_EPI_MUL_AUX1) {
+            v[r] *= a1;
+          } else if (p.epi == PP_EPI_ADD_AUX1) {
+            v[r] += a1;
+          } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
+            const float s = v[r] + a1;
+            v[r] = s > 0.f ? s : 0.f;
+          } else if (p.epi == PP_EPI_GRU) {
+            const float h = to_f32(aux2[m * p.aux2_ldc + cc]);
+            v[r] = (1.f - a1) * h + a1 * v[r];
+          }
+        }
+      }
+      OT* dst = out + m * p.out_ldc + c;
+      const bool vec_ok = (c + 3 < p.Cout) && ((p.out_ldc & 3) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(OT) - 1)) == 0);
+      if (vec_ok) {
+        if constexpr (sizeof(OT) == 2) {
+          h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<h4*>(dst) = o;
+        } else {
+          f4 o = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f4*>(dst) = o;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c + r < p.Cout) dst[r] = from_f32<OT>(v[r]);
+      }
+    }
+  }
+}
+
+template <typename T, typename OT, int WC, int WP, int TC, int TP>
+static int launch_cfg(void* stream, const ConvK& k, int Z) {
+  constexpr int BC = WC * TC * 16;
+  constexpr int BP = WP * TP * 16;
+  constexpr int LDK = 32 + 16 / (int)sizeof(T);
+  const size_t smem = (size_t)2 * (BC + BP) * LDK * sizeof(T);
+  dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
+  pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP>), smem);
+  PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP>), grid, dim3(256), smem, stream, k);
+  return pp_check_launch("pp_conv2d");
+}
+
+template <typename T, typename OT>
+static int launch_by_cout(void* stream, const ConvK& k, int Z) {
+  if (k.Cout > 64) return launch_cfg<T, OT, 2, 2, 4, 4>(stream, k, Z);   // 128 x 128
+  if (k.Cout > 32) return launch_cfg<T, OT, 1, 4, 4, 2>(stream, k, Z);   //  64 x 128
+  if (k.Cout > 16) return launch_cfg<T, OT, 1, 4, 2, 2>(stream, k, Z);   //  32 x 128
+  return launch_cfg<T, OT, 1, 4, 1, 4>(stream, k, Z);                    //  16 x 256
+}
+
+}  // namespace pp
+
+extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
+  using namespace pp;
+  if (!p) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: null params");
+  if (p->nseg < 1 || p->nseg > PP_MAX_SEG) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: nseg out of range");
+  if (p->dtype != PP_F32 && p->dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: dtype");
+  if (p->out_dtype != PP_F32 && p->out_dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: out_dtype");
+  if (!p->weight || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: null weight/out");
+  if (p->Z < 1 || p->Z > 65535) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: Z out of range");
+  if (p->epi != PP_EPI_NONE && !p->aux1) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: epilogue needs aux1");
+  if (p->epi == PP_EPI_GRU && !p->aux2) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: GRU epilogue needs aux2");
+  const int epp = p->dtype == PP_F16 ? 8 : 4;
+  ConvK k;
+  memset(&k, 0, sizeof(k));
+  int cpt = 0;
+  for (int s = 0; s < p->nseg; ++s) {
+    if (!p->in_ptr[s]) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: null input segment");
+    if (p->in_C[s] <= 0 || (p->in_C[s] % epp) != 0)
+      return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: segment channels must be a positive multiple of 16 bytes");
+    if ((p->in_ldc[s] % epp) != 0 || (p->in_zoff[s] % epp) != 0)
+      return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: segment pitch / z offset must be 16-byte multiples");
+    if ((reinterpret_cast<uintptr_t>(p->in_ptr[s]) & 15) != 0)
+      return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: segment base must be 16-byte aligned");
+    k.in_ptr[s] = p->in_ptr[s];
+    k.in_C[s] = (int)p->in_C[s];
+    k.in_ldc[s] = (int)p->in_ldc[s];
+    k.in_zoff[s] = p->in_zoff[s];
+    k.seg_chunks[s] = (int)((p->in_C[s] + 31) / 32);
+    cpt += k.seg_chunks[s];
+  }
+  if ((reinterpret_cast<uintptr_t>(p->weight) & 15) != 0)
+    return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: weight must be 16-byte aligned");
+  k.nseg = p->nseg;
+  k.N = (int)p->N; k.H = (int)p->H; k.W = (int)p->W; k.Ho = (int)p->Ho; k.Wo = (int)p->Wo;
+  k.kh = p->kh; k.kw = p->kw; k.sh = p->sh; k.sw = p->sw; k.ph = p->ph; k.pw = p->pw; k.dh = p->dh; k.dw = p->dw;
+  if (k.kh < 1 || k.kw < 1 || k.sh < 1 || k.sw < 1 || k.dh < 1 || k.dw < 1)
+    return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: bad kernel geometry");
+  k.pad_mode = p->pad_mode;
+  k.weight = p->weight; k.w_zoff = p->w_zoff;
+  k.chunks_per_tap = cpt;
+  k.nchunks = cpt * k.kh * k.kw;
+  k.Kp = k.nchunks * 32;
+  k.bias = reinterpret_cast<const float*>(p->bias); k.bias_zoff = p->bias_zoff;
+  k.Cout = (int)p->Cout;
+  k.M = p->N * p->Ho * p->Wo;
+  if (k.M <= 0 || k.Cout <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: empty problem");
+  k.out = p->out; k.out_ldc = (int)p->out_ldc; k.out_zoff = p->out_zoff;
+  k.act = p->act; k.act2 = p->act2; k.act_split = p->act_split;
+  k.act_param = p->act_param; k.out_scale = p->out_scale;
+  k.epi = p->epi;
+  k.aux1 = p->aux1; k.aux1_ldc = (int)p->aux1_ldc; k.aux1_zoff = p->aux1_zoff;
+  k.aux2 = p->aux2; k.aux2_ldc = (int)p->aux2_ldc; k.aux2_zoff = p->aux2_zoff;
+  const int Z = (int)p->Z;
+  if (p->dtype == PP_F16) {
+    if (p->out_dtype == PP_F16) return launch_by_cout<half_t, half_t>(stream, k, Z);
+    return launch_by_cout<half_t, float>(stream, k, Z);
+  }
+  if (p->out_dtype == PP_F16) return launch_by_cout<float, half_t>(stream, k, Z);
+  return launch_by_cout<float, float>(stream, k, Z);
+}

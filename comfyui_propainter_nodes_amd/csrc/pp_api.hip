@@ -1,0 +1,51 @@
+// pp_api.hip -- library-level entry points of libpropainter_mi355 (version, errors, ABI self-check).
+#include "pp_device.h"
+#include "pp_host.h"
+
+#include <stdio.h>
+
+namespace pp {
+
+static thread_local char g_err[512] = {0};
+
+int pp_fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+  return code;
+}
+
+int pp_check_launch(const char* what) {
+#ifndef PP_EMU
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", what, hipGetErrorString(e));
+    return PP_ERR_LAUNCH;
+  }
+#else
+  (void)what;
+#endif
+  return PP_OK;
+}
+
+void pp_allow_big_lds(const void* func, size_t bytes) {
+#ifndef PP_EMU
+  if (bytes > 48 * 1024) hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+#else
+  (void)func;
+  (void)bytes;
+#endif
+}
+
+}  // namespace pp
+
+extern "C" int32_t pp_version(void) { return PP_ABI_VERSION; }
+
+extern "C" const char* pp_last_error(void) { return pp::g_err; }
+
+#define PP_SIZEOF_CASE(T) \
+  if (strcmp(name, #T) == 0) return (int64_t)sizeof(T);
+
+extern "C" int64_t pp_struct_size(const char* name) {
+  if (!name) return -1;
+  PP_SIZEOF_CASE(pp_conv2d_params)
+  return -1;
+}

@@ -1,0 +1,139 @@
+// pp_device.h -- device-side vocabulary shared by every kernel of libpropainter_mi355.
+//
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, MFMA fragments as documented in
+// /opt/skills/guides/cdna_hip_programming.md section 3.  When PP_EMU is defined (tests only,
+// tests/emu/) the same sources are compiled for x86 and the wave-level primitives below
+// are replaced by rendezvous emulations with identical lane->element maps.
+#pragma once
+
+#ifdef PP_EMU
+#include "pp_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define PP_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+extern __shared__ __attribute__((aligned(16))) unsigned char pp_dyn_smem_[];
+#define PP_DYN_SMEM (pp_dyn_smem_)
+#endif
+
+#include <stdint.h>
+
+namespace pp {
+
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------------
+// MFMA wrappers.
+//   16x16x32 f16 : lane l holds A[row = l&15][k = 8*(l>>4) .. +7] and
+//                  B[k = 8*(l>>4) .. +7][col = l&15];
+//   16x16x4  f32 : lane l holds A[row = l&15][k = l>>4], B[k = l>>4][col = l&15];
+//   C/D (both)   : lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3.
+// ---------------------------------------------------------------------------------------
+#ifndef PP_EMU
+__device__ __forceinline__ f4 mfma_16x16x32_f16(h8 a, h8 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f4 mfma_16x16x4_f32(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+#else
+inline f4 mfma_16x16x32_f16(h8 a, h8 b, f4 c) {
+  struct Slot {
+    h8 a, b;
+    unsigned char pad[32];
+  };
+  Slot* s = reinterpret_cast<Slot*>(pp_emu::wave_scratch());
+  const int l = pp_emu::cur->lane;
+  s[l].a = a;
+  s[l].b = b;
+  pp_emu::wave_sync();
+  const int col = l & 15;
+  f4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (l >> 4) + r;
+    float acc = 0.f;
+    for (int g = 0; g < 4; ++g) {
+      const h8 av = s[row + 16 * g].a;
+      const h8 bv = s[col + 16 * g].b;
+      for (int j = 0; j < 8; ++j) acc += (float)av[j] * (float)bv[j];
+    }
+    d[r] += acc;
+  }
+  pp_emu::wave_sync();
+  return d;
+}
+inline f4 mfma_16x16x4_f32(float a, float b, f4 c) {
+  struct Slot {
+    float a, b;
+    unsigned char pad[56];
+  };
+  Slot* s = reinterpret_cast<Slot*>(pp_emu::wave_scratch());
+  const int l = pp_emu::cur->lane;
+  s[l].a = a;
+  s[l].b = b;
+  pp_emu::wave_sync();
+  const int col = l & 15;
+  f4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (l >> 4) + r;
+    float acc = d[r];
+    for (int g = 0; g < 4; ++g) acc = fmaf(s[row + 16 * g].a, s[col + 16 * g].b, acc);
+    d[r] = acc;
+  }
+  pp_emu::wave_sync();
+  return d;
+}
+inline float shfl_xor(float v, int mask) {
+  float* s = reinterpret_cast<float*>(pp_emu::wave_scratch());
+  const int l = pp_emu::cur->lane;
+  s[l * 16] = v;
+  pp_emu::wave_sync();
+  const float r = s[((l ^ mask) & 63) * 16];
+  pp_emu::wave_sync();
+  return r;
+}
+inline float shfl_idx(float v, int src) {
+  float* s = reinterpret_cast<float*>(pp_emu::wave_scratch());
+  const int l = pp_emu::cur->lane;
+  s[l * 16] = v;
+  pp_emu::wave_sync();
+  const float r = s[(src & 63) * 16];
+  pp_emu::wave_sync();
+  return r;
+}
+inline int lane_id() { return pp_emu::cur->lane; }
+#endif
+
+// ---------------------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(half_t v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) {
+  return v;
+}
+template <>
+__device__ __forceinline__ half_t from_f32<half_t>(float v) {
+  return (half_t)v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__device__ __forceinline__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace pp

@@ -1,0 +1,264 @@
+"""Thin host-side wrappers over the C ABI: torch tensors in, kernel launches out.
+
+PyTorch is used only for device memory and streams.  Every activation handled here is
+channels-last `[N, H, W, C]`; a view whose last-dim slice is narrower than its pitch
+(`t[..., a:b]`) is how channel concatenation is expressed without copies.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import lib as _lib
+
+PP_F32, PP_F16 = _lib.CONSTS["PP_F32"], _lib.CONSTS["PP_F16"]
+ACT = {
+    None: _lib.CONSTS["PP_ACT_NONE"],
+    "none": _lib.CONSTS["PP_ACT_NONE"],
+    "relu": _lib.CONSTS["PP_ACT_RELU"],
+    "leaky": _lib.CONSTS["PP_ACT_LEAKY"],
+    "sigmoid": _lib.CONSTS["PP_ACT_SIGMOID"],
+    "tanh": _lib.CONSTS["PP_ACT_TANH"],
+    "gelu": _lib.CONSTS["PP_ACT_GELU"],
+}
+EPI = {
+    None: _lib.CONSTS["PP_EPI_NONE"],
+    "none": _lib.CONSTS["PP_EPI_NONE"],
+    "mul": _lib.CONSTS["PP_EPI_MUL_AUX1"],
+    "add": _lib.CONSTS["PP_EPI_ADD_AUX1"],
+    "add_relu": _lib.CONSTS["PP_EPI_ADD_AUX1_RELU"],
+    "gru": _lib.CONSTS["PP_EPI_GRU"],
+}
+PAD = {"zeros": _lib.CONSTS["PP_PAD_ZEROS"], "replicate": _lib.CONSTS["PP_PAD_REPLICATE"]}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return PP_F32
+    if dt == torch.float16:
+        return PP_F16
+    if dt == torch.uint8:
+        return _lib.CONSTS["PP_U8"]
+    if dt == torch.int32:
+        return _lib.CONSTS["PP_I32"]
+    raise TypeError(f"unsupported dtype {dt}")
+
+
+def stream_handle(t: torch.Tensor) -> int:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return 0
+
+
+def check_device(*tensors: torch.Tensor) -> None:
+    """The gfx950 library takes device pointers only; the emulator (tests) takes host pointers."""
+    L = _lib.current()
+    for t in tensors:
+        if t is None:
+            continue
+        if L.is_emulator:
+            if t.is_cuda:
+                raise RuntimeError("emulator library loaded but a CUDA tensor was passed")
+        elif not t.is_cuda:
+            raise RuntimeError(
+                "libpropainter_mi355 needs tensors on the MI355X (got a CPU tensor); there is no CPU fallback"
+            )
+
+
+def nhwc_view(t: torch.Tensor) -> tuple[int, int, int, int, int]:
+    """Validate a channels-last view; return (N, H, W, C, ldc)."""
+    if t.dim() != 4:
+        raise ValueError(f"expected [N,H,W,C], got {tuple(t.shape)}")
+    n, h, w, c = t.shape
+    ldc = t.stride(2)
+    if c > 1 and t.stride(3) != 1:
+        raise ValueError("channel dim must be unit-stride")
+    if ldc < c:
+        raise ValueError(f"bad channel pitch {ldc} for {c} channels")
+    if h > 1 and t.stride(1) != w * ldc:
+        raise ValueError(f"rows must be dense: stride {t.stride()} shape {tuple(t.shape)}")
+    if n > 1 and t.stride(0) != h * w * ldc:
+        raise ValueError(f"images must be dense: stride {t.stride()} shape {tuple(t.shape)}")
+    return n, h, w, c, ldc
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def pack_conv_weight(w: torch.Tensor, seg_channels: list[int], dtype: torch.dtype,
+                     seg_valid: list[int] | None = None) -> torch.Tensor:
+    """Repack a torch conv weight `[Cout, Cin, kh, kw]` to `[Cout][tap][seg][c pad 32]`.
+
+    `seg_channels[s]` is the channel count the kernel will read from segment s (a multiple of
+    the 16-byte piece); `seg_valid[s]` (<= seg_channels[s]) is how many of those carry real
+    weights, the rest are zero (used when a source tensor is channel-padded).
+    """
+    cout, cin, kh, kw = w.shape
+    seg_valid = seg_valid or seg_channels
+    if sum(seg_valid) != cin:
+        raise ValueError(f"segments {seg_valid} do not add up to Cin={cin}")
+    kp = sum(pad32(c) for c in seg_channels)
+    out = torch.zeros(cout, kh * kw, kp, dtype=torch.float32)
+    wt = w.detach().float().permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    src = 0
+    dst = 0
+    for c, v in zip(seg_channels, seg_valid):
+        out[:, :, dst:dst + v] = wt[:, :, src:src + v]
+        src += v
+        dst += pad32(c)
+    return out.reshape(cout, kh * kw * kp).to(dtype).contiguous()
+
+
+@dataclass
+class ConvSpec:
+    """Geometry + packed parameters of one convolution / linear layer."""
+
+    weight: torch.Tensor          # packed [Cout_total, Kp]
+    bias: torch.Tensor | None     # fp32 [Cout_total]
+    seg_channels: list[int]       # per-group channels read from each segment
+    cout: int                     # per group
+    kh: int = 1
+    kw: int = 1
+    sh: int = 1
+    sw: int = 1
+    ph: int = 0
+    pw: int = 0
+    dh: int = 1
+    dw: int = 1
+    groups: int = 1
+    pad_mode: str = "zeros"
+
+    def to(self, device) -> "ConvSpec":
+        self.weight = self.weight.to(device)
+        if self.bias is not None:
+            self.bias = self.bias.to(device)
+        return self
+
+    def out_hw(self, h: int, w: int) -> tuple[int, int]:
+        ho = (h + 2 * self.ph - self.dh * (self.kh - 1) - 1) // self.sh + 1
+        wo = (w + 2 * self.pw - self.dw * (self.kw - 1) - 1) // self.sw + 1
+        return ho, wo
+
+
+def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, *, stride=1, padding=0,
+                   dilation=1, groups=1, seg_channels=None, seg_valid=None, pad_mode="zeros") -> ConvSpec:
+    def pair(v):
+        return (v, v) if isinstance(v, int) else tuple(v)
+
+    cout, cin_g, kh, kw = w.shape
+    sh, sw = pair(stride)
+    ph, pw = pair(padding)
+    dh, dw = pair(dilation)
+    seg_channels = seg_channels or [cin_g]
+    packed = pack_conv_weight(w, seg_channels, dtype, seg_valid)
+    bias = b.detach().float().contiguous() if b is not None else None
+    return ConvSpec(packed, bias, list(seg_channels), cout // groups, kh, kw, sh, sw, ph, pw, dh, dw, groups, pad_mode)
+
+
+def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
+           act2=None, act_split=0, out_scale=0.0, epi=None, aux1=None, aux2=None,
+           in_zoff: list[int] | None = None, out_zoff: int | None = None) -> torch.Tensor:
+    """Launch pp_conv2d.  `inputs` are channels-last views (the K segments), `out` a
+    channels-last view `[N, Ho, Wo, >=Cout*groups]` that receives the result."""
+    L = _lib.current()
+    check_device(*inputs, out, aux1, aux2, spec.weight)
+    P = _lib.STRUCTS["pp_conv2d_params"]()
+    x0 = inputs[0]
+    n, h, w, _, _ = nhwc_view(x0)
+    P.dtype = dtype_code(x0.dtype)
+    P.out_dtype = dtype_code(out.dtype)
+    if spec.weight.dtype != x0.dtype:
+        raise TypeError("weight dtype must match the input dtype")
+    P.nseg = len(inputs)
+    P.pad_mode = PAD[spec.pad_mode]
+    if len(inputs) != len(spec.seg_channels):
+        raise ValueError("number of input segments does not match the packed weight")
+    g = spec.groups
+    for s, t in enumerate(inputs):
+        tn, th, tw, tc, ldc = nhwc_view(t)
+        if (tn, th, tw) != (n, h, w):
+            raise ValueError("all segments must share N,H,W")
+        if t.dtype != x0.dtype:
+            raise TypeError("all segments must share a dtype")
+        cs = spec.seg_channels[s]
+        if tc != cs * g:
+            raise ValueError(f"segment {s}: expected {cs * g} channels, got {tc}")
+        P.in_ptr[s] = t.data_ptr()
+        P.in_C[s] = cs
+        P.in_ldc[s] = ldc
+        P.in_zoff[s] = in_zoff[s] if in_zoff is not None else (cs if g > 1 else 0)
+    ho, wo = spec.out_hw(h, w)
+    on, oh, ow, oc, oldc = nhwc_view(out)
+    if (on, oh, ow) != (n, ho, wo) or oc < spec.cout * g:
+        raise ValueError(f"bad output view {tuple(out.shape)} for conv result {(n, ho, wo, spec.cout * g)}")
+    P.N, P.H, P.W, P.Ho, P.Wo = n, h, w, ho, wo
+    P.kh, P.kw, P.sh, P.sw = spec.kh, spec.kw, spec.sh, spec.sw
+    P.ph, P.pw, P.dh, P.dw = spec.ph, spec.pw, spec.dh, spec.dw
+    P.weight = spec.weight.data_ptr()
+    P.w_zoff = spec.cout * spec.weight.shape[1] if g > 1 else 0
+    P.bias = spec.bias.data_ptr() if spec.bias is not None else None
+    P.bias_zoff = spec.cout if g > 1 else 0
+    P.Cout = spec.cout
+    P.Z = g
+    P.out = out.data_ptr()
+    P.out_ldc = oldc
+    P.out_zoff = out_zoff if out_zoff is not None else (spec.cout if g > 1 else 0)
+    P.act = ACT[act]
+    P.act2 = ACT[act2]
+    P.act_split = act_split
+    P.act_param = act_param
+    P.out_scale = out_scale
+    P.epi = EPI[epi]
+    if aux1 is not None:
+        if aux1.dtype != out.dtype:
+            raise TypeError("aux1 dtype must match out dtype")
+        P.aux1 = aux1.data_ptr()
+        P.aux1_ldc = nhwc_view(aux1)[4]
+        P.aux1_zoff = spec.cout if g > 1 else 0
+    if aux2 is not None:
+        if aux2.dtype != out.dtype:
+            raise TypeError("aux2 dtype must match out dtype")
+        P.aux2 = aux2.data_ptr()
+        P.aux2_ldc = nhwc_view(aux2)[4]
+        P.aux2_zoff = spec.cout if g > 1 else 0
+    L.call("pp_conv2d", stream_handle(out), P)
+    return out
+
+
+def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float = 0.0) -> torch.Tensor:
+    """out[z, 0, m, n] = scale * sum_k a[z, 0, m, k] * b[z, n, k]  (pp_conv2d with gridDim.z = batch).
+
+    a: [Z, 1, M, K] channels-last "image" of M pixels, b: [Z, N, K] per-batch "weights"
+    (K a multiple of 32), out: [Z, 1, M, N].  Used for the RAFT all-pairs volume (corr.py:52-60).
+    """
+    L = _lib.current()
+    check_device(a, b, out)
+    z, one, m, k = a.shape
+    zb, n, kb = b.shape
+    if one != 1 or zb != z or kb != k or k % 32 != 0 or not b.is_contiguous():
+        raise ValueError("batched_gemm_nt: bad shapes")
+    if tuple(out.shape) != (z, 1, m, n):
+        raise ValueError("batched_gemm_nt: bad output shape")
+    P = _lib.STRUCTS["pp_conv2d_params"]()
+    P.dtype = dtype_code(a.dtype)
+    P.out_dtype = dtype_code(out.dtype)
+    P.nseg = 1
+    P.in_ptr[0] = a.data_ptr()
+    P.in_C[0] = k
+    P.in_ldc[0] = a.stride(2)
+    P.in_zoff[0] = a.stride(0)
+    P.N, P.H, P.W, P.Ho, P.Wo = 1, 1, m, 1, m
+    P.kh = P.kw = P.sh = P.sw = P.dh = P.dw = 1
+    P.weight = b.data_ptr()
+    P.w_zoff = n * k
+    P.Cout = n
+    P.Z = z
+    P.out = out.data_ptr()
+    P.out_ldc = out.stride(2)
+    P.out_zoff = out.stride(0)
+    P.out_scale = scale
+    L.call("pp_conv2d", stream_handle(out), P)
+    return out

@@ -1,0 +1,97 @@
+"""pp_conv2d (implicit-GEMM MFMA convolution) against torch.nn.functional.conv2d in fp32.
+
+Tolerances: f32 path -> 2e-5 relative to the output scale (exact-f32 MFMA, different summation
+order); f16 path -> 4e-3 relative (f16 operands/outputs, fp32 accumulate)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from comfyui_propainter_nodes_amd import ops
+
+CASES = [
+    # dtype, N, H, W, segC, Cout, k, stride, pad, dil, groups, act
+    (torch.float32, 1, 9, 11, [8], 20, 3, 1, 1, 1, 1, None),
+    (torch.float32, 2, 9, 11, [8, 36], 70, 3, 2, 1, 1, 1, "leaky"),
+    (torch.float32, 1, 7, 13, [4], 130, (1, 5), 1, (0, 2), 1, 1, "sigmoid"),
+    (torch.float16, 2, 9, 11, [8, 40], 130, 3, 1, 2, 2, 1, None),
+    (torch.float16, 1, 12, 10, [16], 6, 1, 1, 0, 1, 1, "relu"),
+    (torch.float16, 1, 12, 10, [16, 8], 24, 3, 1, 1, 1, 2, "tanh"),
+    (torch.float16, 1, 20, 21, [128, 128, 8], 40, 3, 1, 1, 1, 1, "leaky"),
+]
+
+
+def _ref_input(x, segC, groups):
+    if groups == 1:
+        return torch.cat([t.float() for t in x], 3).permute(0, 3, 1, 2)
+    parts = []
+    for g in range(groups):
+        for t_, c in zip(x, segC):
+            parts.append(t_.float()[..., g * c:(g + 1) * c])
+    return torch.cat(parts, 3).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_conv2d_matches_torch(backend, case):
+    dt, N, H, W, segC, Cout, k, s, p, d, groups, act = case
+    dev = backend
+    g = torch.Generator().manual_seed(1234)
+    x = [torch.randn(N, H, W, c * groups, generator=g).to(dt) for c in segC]
+    w = torch.randn(Cout * groups, sum(segC), *((k, k) if isinstance(k, int) else k), generator=g) * 0.1
+    b = torch.randn(Cout * groups, generator=g)
+    spec = ops.make_conv_spec(w, b, dt, stride=s, padding=p, dilation=d, groups=groups, seg_channels=segC).to(dev)
+    ho, wo = spec.out_hw(H, W)
+    # output is a channel slice of a wider buffer: exercises the ldc / slice-view path
+    buf = torch.full((N, ho, wo, Cout * groups + 8), 7.0, dtype=dt, device=dev)
+    out = buf[..., 4:4 + Cout * groups]
+    ops.conv2d(spec, [t.to(dev) for t in x], out, act=act, act_param=0.2)
+    ref = F.conv2d(_ref_input(x, segC, groups), w.to(dt).float(), b, stride=s, padding=p, dilation=d, groups=groups)
+    ref = {None: lambda v: v, "leaky": lambda v: F.leaky_relu(v, 0.2), "relu": F.relu,
+           "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref).permute(0, 2, 3, 1)
+    got = out.float().cpu()
+    tol = (2e-5 if dt == torch.float32 else 4e-3) * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() <= tol
+    # untouched pad channels
+    assert torch.all(buf[..., :4].float().cpu() == 7.0) and torch.all(buf[..., 4 + Cout * groups:].float().cpu() == 7.0)
+
+
+def test_conv2d_epilogues(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(7)
+    dt = torch.float32
+    x = torch.randn(1, 6, 10, 16, generator=g)
+    w = torch.randn(32, 16, 3, 3, generator=g) * 0.1
+    b = torch.randn(32, generator=g)
+    a1 = torch.rand(1, 6, 10, 32, generator=g)
+    a2 = torch.randn(1, 6, 10, 32, generator=g)
+    spec = ops.make_conv_spec(w, b, dt, padding=1).to(dev)
+    base = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    out = torch.empty(1, 6, 10, 32, device=dev)
+    xs = [x.to(dev)]
+    ops.conv2d(spec, xs, out, act="sigmoid", epi="mul", aux1=a1.to(dev))
+    assert torch.allclose(out.cpu(), torch.sigmoid(base) * a1, atol=1e-5)
+    ops.conv2d(spec, xs, out, act="relu", epi="add_relu", aux1=a2.to(dev))
+    assert torch.allclose(out.cpu(), F.relu(F.relu(base) + a2), atol=1e-5)
+    ops.conv2d(spec, xs, out, act="tanh", epi="gru", aux1=a1.to(dev), aux2=a2.to(dev))
+    assert torch.allclose(out.cpu(), (1 - a1) * a2 + a1 * torch.tanh(base), atol=1e-5)
+    ops.conv2d(spec, xs, out, act="tanh", act2="sigmoid", act_split=20, out_scale=5.0)
+    ref = torch.cat([5 * torch.tanh(base[..., :20]), torch.sigmoid(base[..., 20:])], -1)
+    assert torch.allclose(out.cpu(), ref, atol=1e-5)
+
+
+def test_conv2d_replicate_pad_and_batched_gemm(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 9, 8, generator=g)
+    w = torch.randn(16, 8, 5, 5, generator=g) * 0.1
+    spec = ops.make_conv_spec(w, None, torch.float32, stride=2, padding=2, pad_mode="replicate").to(dev)
+    out = torch.empty(2, *spec.out_hw(8, 9), 16, device=dev)
+    ops.conv2d(spec, [x.to(dev)], out)
+    ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2), (2, 2, 2, 2), mode="replicate"), w, stride=2).permute(0, 2, 3, 1)
+    assert torch.allclose(out.cpu(), ref, atol=1e-5)
+    # batched GEMM: the RAFT all-pairs volume form (corr.py:52-60): out[b,p1,p2] = <f1[b,p1], f2[b,p2]>
+    f1 = torch.randn(3, 1, 40, 32, generator=g)
+    f2 = torch.randn(3, 40, 32, generator=g)
+    vol = torch.empty(3, 1, 40, 40, device=dev)
+    ops.batched_gemm_nt(f1.to(dev), f2.to(dev), vol, scale=1.0 / 16)
+    ref = torch.einsum("bpc,bqc->bpq", f1[:, 0], f2) / 16
+    assert torch.allclose(vol.cpu()[:, 0], ref, atol=1e-5)
