@@ -1,0 +1,122 @@
+"""Checkpoint handling: schema, loading, synthetic weights.
+
+The three checkpoints keep the reference's file names and state-dict layout
+(utils/model_utils.py:25,32,43): `raft-things.pth` (keys prefixed `module.`),
+`recurrent_flow_completion.pth`, `ProPainter.pth`, looked up in `<package root>/weights/`.
+`weights_spec.json` is that layout (name -> shape) and is enforced strictly, like the
+reference's `load_state_dict(strict=True)`.
+
+There is no network in the build/bench environment, so `synth_state_dicts(seed)` produces
+seeded random weights of the exact architecture (variance-preserving so that activations,
+deformable offsets and attention logits are all exercised; the reference's own default init
+collapses the generator output to ~0).
+"""
+from __future__ import annotations
+
+import json
+import math
+from pathlib import Path
+
+import torch
+
+PKG = Path(__file__).resolve().parent
+WEIGHT_DIR = PKG.parent / "weights"
+FILES = {"raft": "raft-things.pth", "rfc": "recurrent_flow_completion.pth", "gen": "ProPainter.pth"}
+
+with open(PKG / "weights_spec.json") as _f:
+    SPEC: dict[str, dict[str, list[int]]] = json.load(_f)
+
+
+def valid_ind_rolled(window=(5, 9)) -> torch.Tensor:
+    """Index buffer of the 148 'rolled' neighbour keys (sparse_transformer.py:184-197)."""
+    wh, ww = window
+    eh, ew = (wh + 1) // 2, (ww + 1) // 2
+    masks = []
+    for top, left in ((True, True), (True, False), (False, True), (False, False)):
+        m = torch.ones(wh, ww)
+        rs = slice(0, wh - eh) if top else slice(eh, wh)
+        cs = slice(0, ww - ew) if left else slice(ew, ww)
+        m[rs, cs] = 0
+        masks.append(m)
+    return torch.stack(masks, 0).flatten().nonzero(as_tuple=False).view(-1)
+
+
+def _synth_tensor(name: str, shape: list[int], g: torch.Generator) -> torch.Tensor:
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return torch.zeros((), dtype=torch.int64)
+    if leaf == "valid_ind_rolled":
+        return valid_ind_rolled()
+    if leaf == "running_mean":
+        return torch.randn(shape, generator=g) * 0.1
+    if leaf == "running_var":
+        return torch.rand(shape, generator=g) + 0.5
+    if leaf == "bias":
+        return torch.randn(shape, generator=g) * 0.05
+    if leaf == "weight" and len(shape) == 1:  # BatchNorm / LayerNorm scale
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if "pool_layer" in name:
+        return 1.0 / 16.0 + 0.01 * torch.randn(shape, generator=g)
+    fan_in = 1
+    for d in shape[1:]:
+        fan_in *= d
+    gain = 1.0 if len(shape) == 2 else 1.4
+    if "conv_offset.6" in name:
+        gain = 0.5
+    if "flow_head.conv2" in name:  # keep the synthetic RAFT well-conditioned (sub-pixel updates per iteration)
+        gain = 0.1
+    if name.startswith("decoder.6"):  # keep the synthetic generator's tanh un-saturated
+        gain = 0.25
+    if name.endswith("ss.embedding.weight") or name.endswith("sc.embedding.weight"):
+        gain = 1.0
+    return torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
+
+
+def synth_state_dicts(seed: int = 0) -> dict[str, dict[str, torch.Tensor]]:
+    """Seeded random weights with the exact checkpoint layout (fp32, CPU)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {net: {k: _synth_tensor(k, shp, g) for k, shp in spec.items()} for net, spec in SPEC.items()}
+    # RAFT registers the stride-2 blocks' norm3 twice (`norm3` and `downsample.1` are one module,
+    # extractor.py:20-47): a real checkpoint carries identical tensors under both names.
+    for k in list(out["raft"]):
+        if ".downsample.1." in k:
+            out["raft"][k] = out["raft"][k.replace(".downsample.1.", ".norm3.")].clone()
+    return out
+
+
+def check_state_dict(net: str, sd: dict[str, torch.Tensor]) -> None:
+    spec = SPEC[net]
+    missing = [k for k in spec if k not in sd]
+    extra = [k for k in sd if k not in spec]
+    if missing or extra:
+        raise RuntimeError(f"{FILES[net]}: state dict mismatch, missing={missing[:4]} unexpected={extra[:4]}")
+    for k, shp in spec.items():
+        if list(sd[k].shape) != shp:
+            raise RuntimeError(f"{FILES[net]}: {k} has shape {list(sd[k].shape)}, expected {shp}")
+
+
+def weights_available(weight_dir: Path = WEIGHT_DIR) -> bool:
+    return all((weight_dir / f).exists() for f in FILES.values())
+
+
+def load_state_dicts(weight_dir: Path = WEIGHT_DIR) -> dict[str, dict[str, torch.Tensor]]:
+    """Load the three pretrained checkpoints from `weights/` (no download: there is no network)."""
+    out = {}
+    for net, fname in FILES.items():
+        path = weight_dir / fname
+        if not path.exists():
+            raise FileNotFoundError(
+                f"{path} not found. Place the ProPainter v0.1.0 release checkpoints "
+                f"({', '.join(FILES.values())}) in {weight_dir}."
+            )
+        sd = torch.load(path, map_location="cpu")
+        check_state_dict(net, sd)
+        out[net] = {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
+    return out
+
+
+def get_state_dicts(seed: int = 0) -> tuple[dict[str, dict[str, torch.Tensor]], str]:
+    """Real checkpoints when present, else seeded synthetic ones. Returns (dicts, provenance)."""
+    if weights_available():
+        return load_state_dicts(), "pretrained"
+    return synth_state_dicts(seed), f"synthetic(seed={seed})"

@@ -1,0 +1,144 @@
+"""Mint the committed golden fixtures from the REFERENCE ITSELF (build container only).
+
+Runs daniabib/ComfyUI_ProPainter_Nodes (imported from /root/reference through the shims in
+ref_import.py) on CPU fp32 with seeded synthetic weights (comfyui_propainter_nodes_amd.weights.synth_state_dicts)
+and seeded synthetic clips, dumps stage-level tensors to tests/golden/*.npz, and first checks that
+oracle/ reproduces every dumped tensor (the oracle pin).  Usage:
+
+    python tests/golden/make_golden.py            # regenerate all fixtures
+
+The fixtures travel to the GPU box; /root/reference does not.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(HERE))
+
+import ref_import  # noqa: E402
+from comfyui_propainter_nodes_amd import synth, weights  # noqa: E402
+from oracle import generator as OG  # noqa: E402
+from oracle import pipeline as OP  # noqa: E402
+from oracle import raft as OR  # noqa: E402
+from oracle import rfc as OC  # noqa: E402
+
+
+def build_reference_models(sds):
+    ref = ref_import.load_reference()
+    from reference.model.modules.flow_comp_raft import RAFT_bi
+    from reference.model.propainter import InpaintGenerator
+    from reference.model.recurrent_flow_completion import RecurrentFlowCompleteNet
+    from reference.utils.model_utils import Models
+
+    with tempfile.NamedTemporaryFile(suffix=".pth") as f:
+        torch.save(sds["raft"], f.name)
+        raft = RAFT_bi(f.name, torch.device("cpu"))
+    rfc = RecurrentFlowCompleteNet(None)
+    rfc.load_state_dict(sds["rfc"], strict=True)
+    rfc.eval()
+    gen = InpaintGenerator(model_path=None)
+    gen.load_state_dict(sds["gen"], strict=True)
+    gen.eval()
+    return ref, Models(raft, rfc, gen)
+
+
+def rel_err(a, b):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def run_case(name, T, H, W, *, raft_iter, neighbor_length, ref_stride, subvideo_length, mask_dilates, flow_mask_dilates,
+             seed=0, save=True):
+    sds = weights.synth_state_dicts(seed)
+    ref, models = build_reference_models(sds)
+    import reference.propainter_nodes as RN
+    from reference.propainter_inference import ProPainterConfig, feature_propagation, process_inpainting
+    from reference.utils.image_utils import ImageConfig, convert_image_to_frames, handle_output, prepare_frames_and_masks
+
+    image, mask = synth.synthetic_clip(T, H, W)
+    dev = torch.device("cpu")
+    frames_pil = convert_image_to_frames(image)
+    icfg = ImageConfig(W, H, mask_dilates, flow_mask_dilates, frames_pil[0].size, T)
+    cfg = ProPainterConfig(ref_stride, neighbor_length, subvideo_length, raft_iter, "disable", T, dev, icfg.process_size)
+    frames_t, flow_masks_t, masks_dil_t, original = prepare_frames_and_masks(frames_pil, mask, icfg, dev)
+    with torch.no_grad():
+        gt = models.raft_model(frames_t, iters=raft_iter)
+    uf, um, pred = process_inpainting(models, frames_t, flow_masks_t, masks_dil_t, cfg)
+    # per-window generator outputs (re-run the reference model the way feature_propagation does)
+    sched = OP.window_schedule(T, neighbor_length, ref_stride, subvideo_length)
+    pred_imgs = []
+    with torch.no_grad():
+        for nb, refs in sched:
+            ids = nb + refs
+            pred_imgs.append(models.inpaint_model(uf[:, ids], (pred[0][:, nb[:-1]], pred[1][:, nb[:-1]]), masks_dil_t[:, ids],
+                                                  um[:, ids], len(nb))[0])
+    comp = feature_propagation(models.inpaint_model, uf, um, masks_dil_t, pred, [o.copy() for o in original], cfg)
+    out_img, out_fm, out_md = handle_output(comp, flow_masks_t, masks_dil_t)
+
+    # ---- oracle pin -------------------------------------------------------------------------
+    ocomp, tr = OP.run(sds, frames_t, flow_masks_t, masks_dil_t, [o.copy() for o in original], raft_iter=raft_iter,
+                       neighbor_length=neighbor_length, ref_stride=ref_stride, subvideo_length=subvideo_length,
+                       return_trace=True)
+    report = {
+        "gt_flow_f": rel_err(tr["gt_flows"][0], gt[0]),
+        "gt_flow_b": rel_err(tr["gt_flows"][1], gt[1]),
+        "pred_flow_f": rel_err(tr["pred_flows"][0], pred[0]),
+        "pred_flow_b": rel_err(tr["pred_flows"][1], pred[1]),
+        "updated_frames": rel_err(tr["updated_frames"], uf),
+        "updated_masks": rel_err(tr["updated_masks"], um),
+        "pred_img_max": max(rel_err(a, b) for a, b in zip(tr["pred_imgs"], pred_imgs)),
+        "composed_maxdiff_u8": max(int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max()) for a, b in zip(ocomp, comp)),
+    }
+    print(name, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in report.items()})
+    print("   pred_img std", float(torch.stack([p.std() for p in pred_imgs]).mean()), "flow absmax", float(gt[0].abs().max()),
+          "pred flow absmax", float(pred[0].abs().max()))
+    if save:
+        # inputs are regenerable from the seed (synth.synthetic_clip + host prep); keep the fixtures small
+        np.savez_compressed(
+            HERE / f"{name}.npz",
+            params=np.array([T, H, W, raft_iter, neighbor_length, ref_stride, subvideo_length, mask_dilates,
+                             flow_mask_dilates, seed], dtype=np.int64),
+            frames_u8=np.stack(original, 0).astype(np.uint8),
+            flow_masks=flow_masks_t[0, :, 0].numpy().astype(np.uint8),
+            masks_dilated=masks_dil_t[0, :, 0].numpy().astype(np.uint8),
+            gt_flow_f=gt[0][0].numpy().astype(np.float32), gt_flow_b=gt[1][0].numpy().astype(np.float32),
+            pred_flow_f=pred[0][0].numpy().astype(np.float16), pred_flow_b=pred[1][0].numpy().astype(np.float16),
+            updated_frames=uf[0].numpy().astype(np.float16), updated_masks=um[0, :, 0].numpy().astype(np.uint8),
+            pred_imgs=np.concatenate([p.numpy() for p in pred_imgs], 0).astype(np.float16),
+            out_image=(out_img.numpy() * 255 + 0.5).astype(np.uint8),
+        )
+    return report
+
+
+CASES = {
+    # small end-to-end clip, global reference frames (T <= subvideo_length)
+    "e2e_small": dict(T=6, H=128, W=144, raft_iter=3, neighbor_length=4, ref_stride=2, subvideo_length=80,
+                      mask_dilates=3, flow_mask_dilates=5),
+    # chunked paths: flow completion / image propagation sub-videos with halos, local reference mode
+    "e2e_chunked": dict(T=9, H=128, W=128, raft_iter=2, neighbor_length=4, ref_stride=2, subvideo_length=4,
+                        mask_dilates=2, flow_mask_dilates=3),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="all")
+    ap.add_argument("--no-save", action="store_true")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    for name, kw in CASES.items():
+        if args.case in ("all", name):
+            run_case(name, save=not args.no_save, **kw)
+
+
+if __name__ == "__main__":
+    main()
