@@ -47,5 +47,10 @@ extern "C" const char* pp_last_error(void) { return pp::g_err; }
 extern "C" int64_t pp_struct_size(const char* name) {
   if (!name) return -1;
   PP_SIZEOF_CASE(pp_conv2d_params)
+  PP_SIZEOF_CASE(pp_im2col_params)
+  PP_SIZEOF_CASE(pp_instnorm_params)
+  PP_SIZEOF_CASE(pp_avgpool2x2_params)
+  PP_SIZEOF_CASE(pp_corr_lookup_params)
+  PP_SIZEOF_CASE(pp_convex_upsample_params)
   return -1;
 }

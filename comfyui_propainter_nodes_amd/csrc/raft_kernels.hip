@@ -1,0 +1,330 @@
+// raft_kernels.hip -- the non-GEMM kernels of the RAFT stage (all HBM / gather bound):
+// im2col for tiny-Cin convolutions, instance norm, correlation pyramid pooling, correlation
+// window lookup and convex 8x upsampling.  See include/propainter_mi355.h for the contracts
+// and the reference call sites.
+#include "pp_device.h"
+#include "pp_host.h"
+
+namespace pp {
+
+// ----------------------------------------------------------------------------------------
+// im2col
+// ----------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) im2col_kernel(const TI* __restrict__ in, int in_ldc, int N, int H, int W, int C,
+                                                      int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
+                                                      int pad_mode, TO* __restrict__ out, int Kpad, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx % Kpad);
+  const int64_t m = idx / Kpad;
+  float v = 0.f;
+  if (k < kh * kw * C) {
+    const int c = k % C;
+    const int tap = k / C;
+    const int ky = tap / kw, kx = tap % kw;
+    const int wo = (int)(m % Wo);
+    const int64_t t = m / Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    int y = ho * sh - ph + ky;
+    int x = wo * sw - pw + kx;
+    bool ok = true;
+    if (pad_mode == PP_PAD_REPLICATE) {
+      y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+      x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    } else {
+      ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+    }
+    if (ok) v = to_f32(in[(((int64_t)n * H + y) * W + x) * in_ldc + c]);
+  }
+  out[idx] = from_f32<TO>(v);
+}
+
+// ----------------------------------------------------------------------------------------
+// instance norm (channels-last fp32): partial sums in double, then fused apply
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) instnorm_partial_kernel(const float* __restrict__ x, int x_ldc, int64_t HW,
+                                                               int C, int nchunks, double* __restrict__ partials) {
+  // grid = (nchunks, N); thread t handles channel t % C with pixel lane t / C
+  const int n = (int)blockIdx.y;
+  const int chunk = (int)blockIdx.x;
+  const int tid = (int)threadIdx.x;
+  const int lanes = 256 / C;  // >= 1 (C <= 256)
+  const int c = tid % C;
+  const int pl = tid / C;
+  const int64_t per = (HW + nchunks - 1) / nchunks;
+  const int64_t p0 = (int64_t)chunk * per;
+  const int64_t p1 = p0 + per < HW ? p0 + per : HW;
+  double s = 0.0, ss = 0.0;
+  if (pl < lanes) {
+    const float* base = x + (int64_t)n * HW * x_ldc + c;
+    for (int64_t p = p0 + pl; p < p1; p += lanes) {
+      const double v = (double)base[p * x_ldc];
+      s += v;
+      ss += v * v;
+    }
+  }
+  __shared__ double sh_s[256];
+  __shared__ double sh_ss[256];
+  sh_s[tid] = s;
+  sh_ss[tid] = ss;
+  __syncthreads();
+  if (tid < C) {
+    double a = 0.0, b = 0.0;
+    for (int l = 0; l < lanes; ++l) {
+      a += sh_s[l * C + tid];
+      b += sh_ss[l * C + tid];
+    }
+    double* dst = partials + (((int64_t)n * nchunks + chunk) * C + tid) * 2;
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+__global__ void __launch_bounds__(256) instnorm_apply_kernel(const float* __restrict__ x, int x_ldc,
+                                                             float* __restrict__ y, int y_ldc,
+                                                             const float* __restrict__ skip, int skip_ldc, int64_t HW,
+                                                             int C, int nchunks, const double* __restrict__ partials,
+                                                             float eps, int relu_pre, int relu_post) {
+  const int n = (int)blockIdx.y;
+  const int chunk = (int)blockIdx.x;
+  const int tid = (int)threadIdx.x;
+  __shared__ float sh_mean[256];
+  __shared__ float sh_rstd[256];
+  if (tid < C) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+      const double* src = partials + (((int64_t)n * nchunks + k) * C + tid) * 2;
+      a += src[0];
+      b += src[1];
+    }
+    const double mean = a / (double)HW;
+    double var = b / (double)HW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    sh_mean[tid] = (float)mean;
+    sh_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int lanes = 256 / C;
+  const int c = tid % C;
+  const int pl = tid / C;
+  if (pl >= lanes) return;
+  const int64_t per = (HW + nchunks - 1) / nchunks;
+  const int64_t p0 = (int64_t)chunk * per;
+  const int64_t p1 = p0 + per < HW ? p0 + per : HW;
+  const float mean = sh_mean[c], rstd = sh_rstd[c];
+  for (int64_t p = p0 + pl; p < p1; p += lanes) {
+    const int64_t pix = (int64_t)n * HW + p;
+    float v = (x[pix * x_ldc + c] - mean) * rstd;
+    if (relu_pre) v = v > 0.f ? v : 0.f;
+    if (skip) v += skip[pix * skip_ldc + c];
+    if (relu_post) v = v > 0.f ? v : 0.f;
+    y[pix * y_ldc + c] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// 2x2 average pooling of the correlation planes
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) avgpool2x2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         int H, int W, int Ho, int Wo, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int xo = (int)(idx % Wo);
+  const int64_t t = idx / Wo;
+  const int yo = (int)(t % Ho);
+  const int64_t b = t / Ho;
+  const float* src = in + (b * H + 2 * yo) * W + 2 * xo;
+  out[idx] = (src[0] + src[1] + src[W] + src[W + 1]) * 0.25f;
+}
+
+// ----------------------------------------------------------------------------------------
+// correlation window lookup
+// ----------------------------------------------------------------------------------------
+struct LookupK {
+  const float* pyr[4];
+  int ph[4];
+  int pw[4];
+  const float* flow;
+  int flow_ldc;
+  float* out;
+  int out_ldc;
+  int h, w;
+  int64_t total;  // N*h*w*324
+};
+
+__device__ __forceinline__ float sample_plane(const float* __restrict__ plane, int H, int W, float x, float y) {
+  // grid_sample(bilinear, zeros, align_corners=True) on pixel coordinates after the
+  // normalise -> unnormalise round trip of bilinear_sampler (RAFT/utils/utils.py:69-74)
+  const float xn = 2.f * x / (float)(W - 1) - 1.f;
+  const float yn = 2.f * y / (float)(H - 1) - 1.f;
+  const float ix = ((xn + 1.f) / 2.f) * (float)(W - 1);
+  const float iy = ((yn + 1.f) / 2.f) * (float)(H - 1);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float ax = ix - fx, ay = iy - fy;
+  float v = 0.f;
+  const bool xin0 = (x0 >= 0) && (x0 < W), xin1 = (x0 + 1 >= 0) && (x0 + 1 < W);
+  const bool yin0 = (y0 >= 0) && (y0 < H), yin1 = (y0 + 1 >= 0) && (y0 + 1 < H);
+  if (yin0) {
+    const float* r = plane + (int64_t)y0 * W;
+    if (xin0) v += r[x0] * (1.f - ax) * (1.f - ay);
+    if (xin1) v += r[x0 + 1] * ax * (1.f - ay);
+  }
+  if (yin1) {
+    const float* r = plane + (int64_t)(y0 + 1) * W;
+    if (xin0) v += r[x0] * (1.f - ax) * ay;
+    if (xin1) v += r[x0 + 1] * ax * ay;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= k.total) return;
+  const int ch = (int)(idx % 324);
+  const int64_t pix = idx / 324;  // n*h*w + y*w + x
+  const int lvl = ch / 81;
+  const int r = ch - lvl * 81;
+  const int i = r / 9, j = r - i * 9;
+  const int hw = k.h * k.w;
+  const int p = (int)(pix % hw);
+  const int py = p / k.w, px = p - py * k.w;
+  const float fx = k.flow[pix * k.flow_ldc + 0];
+  const float fy = k.flow[pix * k.flow_ldc + 1];
+  const float scale = 1.f / (float)(1 << lvl);
+  const float cx = ((float)px + fx) * scale + (float)(i - 4);
+  const float cy = ((float)py + fy) * scale + (float)(j - 4);
+  const int H = k.ph[lvl], W = k.pw[lvl];
+  const float* plane = k.pyr[lvl] + pix * (int64_t)H * W;
+  k.out[pix * k.out_ldc + ch] = sample_plane(plane, H, W, cx, cy);
+}
+
+// ----------------------------------------------------------------------------------------
+// convex upsampling: one 64-thread group per coarse pixel, thread = (a, b) of the 8x8 patch
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) convex_upsample_kernel(const float* __restrict__ mask, int mask_ldc,
+                                                              const float* __restrict__ flow, int flow_ldc,
+                                                              float* __restrict__ out, int h, int w, int64_t ncoarse) {
+  const int64_t cp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cp >= ncoarse) return;
+  const int ab = (int)(threadIdx.x & 63);
+  const int a = ab >> 3, b = ab & 7;
+  const int hw = h * w;
+  const int64_t n = cp / hw;
+  const int p = (int)(cp % hw);
+  const int i = p / w, j = p - i * w;
+  const float* m = mask + cp * mask_ldc + ab;
+  float logit[9];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    logit[t] = m[t * 64];
+    mx = fmaxf(mx, logit[t]);
+  }
+  float den = 0.f, ux = 0.f, uy = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float e = __expf(logit[t] - mx);
+    den += e;
+    const int yy = i + t / 3 - 1, xx = j + t % 3 - 1;
+    if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+      const float* f = flow + (n * hw + (int64_t)yy * w + xx) * flow_ldc;
+      ux += e * 8.f * f[0];
+      uy += e * 8.f * f[1];
+    }
+  }
+  const int64_t W8 = 8 * (int64_t)w;
+  const int64_t o = ((n * 8 * h + (8 * i + a)) * W8 + (8 * j + b)) * 2;
+  out[o] = ux / den;
+  out[o + 1] = uy / den;
+}
+
+static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace pp
+
+extern "C" int32_t pp_im2col(void* stream, const pp_im2col_params* p) {
+  using namespace pp;
+  if (!p || !p->in || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_im2col: null argument");
+  if (p->Kpad < (int64_t)p->kh * p->kw * p->C) return pp_fail(PP_ERR_BAD_ARG, "pp_im2col: Kpad too small");
+  const int64_t total = p->N * p->Ho * p->Wo * p->Kpad;
+  if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_im2col: empty problem");
+#define PP_IM2COL(TI, TO)                                                                                         \
+  PP_LAUNCH((im2col_kernel<TI, TO>), dim3(blocks_for(total)), dim3(256), 0, stream, (const TI*)p->in,            \
+            (int)p->in_ldc, (int)p->N, (int)p->H, (int)p->W, (int)p->C, (int)p->Ho, (int)p->Wo, p->kh, p->kw,     \
+            p->sh, p->sw, p->ph, p->pw, p->pad_mode, (TO*)p->out, (int)p->Kpad, total)
+  if (p->dtype == PP_F32 && p->out_dtype == PP_F32) {
+    PP_IM2COL(float, float);
+  } else if (p->dtype == PP_F32 && p->out_dtype == PP_F16) {
+    PP_IM2COL(float, half_t);
+  } else if (p->dtype == PP_F16 && p->out_dtype == PP_F16) {
+    PP_IM2COL(half_t, half_t);
+  } else {
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_im2col: dtype combination");
+  }
+#undef PP_IM2COL
+  return pp_check_launch("pp_im2col");
+}
+
+extern "C" int32_t pp_instnorm(void* stream, const pp_instnorm_params* p) {
+  using namespace pp;
+  if (!p || !p->x || !p->y || !p->partials) return pp_fail(PP_ERR_BAD_ARG, "pp_instnorm: null argument");
+  if (p->C < 1 || p->C > 256) return pp_fail(PP_ERR_UNSUPPORTED, "pp_instnorm: C must be in [1,256]");
+  if (p->nchunks < 1 || p->nchunks > 65535 || p->N < 1 || p->N > 65535)
+    return pp_fail(PP_ERR_BAD_ARG, "pp_instnorm: bad nchunks/N");
+  dim3 grid((unsigned)p->nchunks, (unsigned)p->N);
+  PP_LAUNCH(instnorm_partial_kernel, grid, dim3(256), 0, stream, (const float*)p->x, (int)p->x_ldc, p->HW, (int)p->C,
+            (int)p->nchunks, (double*)p->partials);
+  int rc = pp_check_launch("pp_instnorm(partial)");
+  if (rc) return rc;
+  PP_LAUNCH(instnorm_apply_kernel, grid, dim3(256), 0, stream, (const float*)p->x, (int)p->x_ldc, (float*)p->y,
+            (int)p->y_ldc, (const float*)p->skip, (int)p->skip_ldc, p->HW, (int)p->C, (int)p->nchunks,
+            (const double*)p->partials, p->eps, p->relu_pre, p->relu_post);
+  return pp_check_launch("pp_instnorm(apply)");
+}
+
+extern "C" int32_t pp_avgpool2x2(void* stream, const pp_avgpool2x2_params* p) {
+  using namespace pp;
+  if (!p || !p->in || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_avgpool2x2: null argument");
+  const int Ho = (int)(p->H / 2), Wo = (int)(p->W / 2);
+  const int64_t total = p->B * Ho * Wo;
+  if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_avgpool2x2: empty problem");
+  PP_LAUNCH(avgpool2x2_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, (const float*)p->in, (float*)p->out,
+            (int)p->H, (int)p->W, Ho, Wo, total);
+  return pp_check_launch("pp_avgpool2x2");
+}
+
+extern "C" int32_t pp_corr_lookup(void* stream, const pp_corr_lookup_params* p) {
+  using namespace pp;
+  if (!p || !p->flow || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_corr_lookup: null argument");
+  LookupK k;
+  for (int l = 0; l < 4; ++l) {
+    if (!p->pyr[l] || p->ph[l] < 2 || p->pw[l] < 2)
+      return pp_fail(PP_ERR_BAD_ARG, "pp_corr_lookup: every pyramid level needs >= 2 rows and columns (H,W >= 128)");
+    k.pyr[l] = (const float*)p->pyr[l];
+    k.ph[l] = (int)p->ph[l];
+    k.pw[l] = (int)p->pw[l];
+  }
+  k.flow = (const float*)p->flow;
+  k.flow_ldc = (int)p->flow_ldc;
+  k.out = (float*)p->out;
+  k.out_ldc = (int)p->out_ldc;
+  k.h = (int)p->h;
+  k.w = (int)p->w;
+  k.total = p->N * p->h * p->w * 324;
+  if (k.total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_corr_lookup: empty problem");
+  PP_LAUNCH(corr_lookup_kernel, dim3(blocks_for(k.total)), dim3(256), 0, stream, k);
+  return pp_check_launch("pp_corr_lookup");
+}
+
+extern "C" int32_t pp_convex_upsample(void* stream, const pp_convex_upsample_params* p) {
+  using namespace pp;
+  if (!p || !p->mask || !p->flow || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_convex_upsample: null argument");
+  const int64_t ncoarse = p->N * p->h * p->w;
+  if (ncoarse <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_convex_upsample: empty problem");
+  PP_LAUNCH(convex_upsample_kernel, dim3((unsigned)((ncoarse + 3) / 4)), dim3(256), 0, stream, (const float*)p->mask,
+            (int)p->mask_ldc, (const float*)p->flow, (int)p->flow_ldc, (float*)p->out, (int)p->h, (int)p->w, ncoarse);
+  return pp_check_launch("pp_convex_upsample");
+}

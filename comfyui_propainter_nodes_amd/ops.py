@@ -262,3 +262,92 @@ def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: 
     P.out_scale = scale
     L.call("pp_conv2d", stream_handle(out), P)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# RAFT-stage kernels
+# --------------------------------------------------------------------------------------------
+def _call(name: str, ref: torch.Tensor, P) -> None:
+    _lib.current().call(name, stream_handle(ref), P)
+
+
+def im2col(x: torch.Tensor, out: torch.Tensor, kh: int, kw: int, *, stride=1, padding=0, pad_mode="zeros") -> torch.Tensor:
+    """x [N,H,W,C] (tiny C) -> out [N,Ho,Wo,Kpad] patch matrix, k = (ky*kw+kx)*C + c."""
+    check_device(x, out)
+    n, h, w, c, ldc = nhwc_view(x)
+    on, ho, wo, kpad, oldc = nhwc_view(out)
+    if oldc != kpad or not out.is_contiguous():
+        raise ValueError("im2col output must be dense")
+    P = _lib.STRUCTS["pp_im2col_params"]()
+    P.dtype, P.out_dtype, P.pad_mode = dtype_code(x.dtype), dtype_code(out.dtype), PAD[pad_mode]
+    P.kh, P.kw, P.sh, P.sw, P.ph, P.pw = kh, kw, stride, stride, padding, padding
+    P.in_ldc = ldc
+    setattr(P, "in", x.data_ptr())
+    P.N, P.H, P.W, P.C, P.Ho, P.Wo = n, h, w, c, ho, wo
+    P.out, P.Kpad = out.data_ptr(), kpad
+    _call("pp_im2col", out, P)
+    return out
+
+
+def instnorm(x: torch.Tensor, y: torch.Tensor, *, relu_pre=False, relu_post=False, skip: torch.Tensor | None = None,
+             eps: float = 1e-5, scratch: torch.Tensor | None = None) -> torch.Tensor:
+    """Instance norm over H*W per (n, c) of a channels-last fp32 tensor, fused pre-ReLU / skip / post-ReLU."""
+    check_device(x, y, skip)
+    n, h, w, c, ldc = nhwc_view(x)
+    nchunks = max(1, min(256, (h * w) // 512))
+    need = n * nchunks * c * 2
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(need, dtype=torch.float64, device=x.device)
+    P = _lib.STRUCTS["pp_instnorm_params"]()
+    P.x, P.x_ldc = x.data_ptr(), ldc
+    P.y, P.y_ldc = y.data_ptr(), nhwc_view(y)[4]
+    if skip is not None:
+        P.skip, P.skip_ldc = skip.data_ptr(), nhwc_view(skip)[4]
+    P.N, P.HW, P.C = n, h * w, c
+    P.relu_pre, P.relu_post = int(relu_pre), int(relu_post)
+    P.partials, P.nchunks, P.eps = scratch.data_ptr(), nchunks, eps
+    _call("pp_instnorm", y, P)
+    return y
+
+
+def avgpool2x2(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """x [B,H,W] fp32 dense -> out [B,H//2,W//2]."""
+    check_device(x, out)
+    b, h, w = x.shape
+    if not x.is_contiguous() or not out.is_contiguous() or tuple(out.shape) != (b, h // 2, w // 2):
+        raise ValueError("avgpool2x2: bad shapes")
+    P = _lib.STRUCTS["pp_avgpool2x2_params"]()
+    setattr(P, "in", x.data_ptr())
+    P.out, P.B, P.H, P.W = out.data_ptr(), b, h, w
+    _call("pp_avgpool2x2", out, P)
+    return out
+
+
+def corr_lookup(pyramid: list[torch.Tensor], flow: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """pyramid[l]: [N, h*w, h_l, w_l] fp32; flow [N,h,w,2] view; out [N,h,w,324] view."""
+    check_device(*pyramid, flow, out)
+    n, h, w, _, fl = nhwc_view(flow)
+    P = _lib.STRUCTS["pp_corr_lookup_params"]()
+    for l, t in enumerate(pyramid):
+        if not t.is_contiguous() or t.shape[0] != n or t.shape[1] != h * w:
+            raise ValueError("corr_lookup: bad pyramid level")
+        P.pyr[l], P.ph[l], P.pw[l] = t.data_ptr(), t.shape[2], t.shape[3]
+    P.flow, P.flow_ldc = flow.data_ptr(), fl
+    P.out, P.out_ldc = out.data_ptr(), nhwc_view(out)[4]
+    P.N, P.h, P.w = n, h, w
+    _call("pp_corr_lookup", out, P)
+    return out
+
+
+def convex_upsample(mask: torch.Tensor, flow: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """mask [N,h,w,576], flow [N,h,w,2] view -> out [N,8h,8w,2] dense fp32."""
+    check_device(mask, flow, out)
+    n, h, w, _, ml = nhwc_view(mask)
+    P = _lib.STRUCTS["pp_convex_upsample_params"]()
+    P.mask, P.mask_ldc = mask.data_ptr(), ml
+    P.flow, P.flow_ldc = flow.data_ptr(), nhwc_view(flow)[4]
+    if not out.is_contiguous() or tuple(out.shape) != (n, 8 * h, 8 * w, 2):
+        raise ValueError("convex_upsample: bad output")
+    P.out, P.N, P.h, P.w = out.data_ptr(), n, h, w
+    _call("pp_convex_upsample", out, P)
+    return out

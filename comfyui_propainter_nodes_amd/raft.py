@@ -1,0 +1,242 @@
+"""RAFT bidirectional optical flow on the MI355X (fp32, like the reference keeps RAFT in fp32:
+utils/model_utils.py:55-56, propainter_inference.py:74).
+
+Host-side scheduling only: every FLOP and gather runs in libpropainter_mi355 kernels.
+Replaces RAFT_bi.forward / RAFT.forward (model/modules/flow_comp_raft.py:39-58,
+RAFT/raft.py:94-152) and compute_flow's clip chunking (propainter_inference.py:61-99) with a
+scheduler designed for 288 GB of HBM:
+
+  * fnet / cnet run ONCE per frame (the reference recomputes both for every pair and direction),
+  * all pair-directions of the clip are batched through every update-block kernel,
+  * the mask head and the convex upsampling run only after the last iteration
+    (the reference evaluates and discards them every iteration, raft.py:141-150),
+  * eval-mode BatchNorm of cnet is folded into the convolution weights.
+
+Results per pair are independent of the reference's clip chunking (instance norm is per
+sample), so only the pair batching is memory-capped (`max_volume_bytes`).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _strip(sd: dict, prefix: str) -> dict:
+    pre = ("module." + prefix) if any(k.startswith("module.") for k in sd) else prefix
+    return {k[len(pre):]: v.float() for k, v in sd.items() if k.startswith(pre) and v.is_floating_point()}
+
+
+def _fold_bn(w, b, p, name):
+    s = p[name + ".weight"].double() / torch.sqrt(p[name + ".running_var"].double() + 1e-5)
+    w2 = (w.double() * s.view(-1, 1, 1, 1)).float()
+    b2 = ((b.double() - p[name + ".running_mean"].double()) * s + p[name + ".bias"].double()).float()
+    return w2, b2
+
+
+class _Encoder:
+    """BasicEncoder (extractor.py:121-193) as a list of conv specs; `kind` = instance | batch."""
+
+    def __init__(self, p: dict, kind: str, device):
+        self.kind = kind
+        dt = torch.float32
+
+        def conv(name, norm=None, **kw):
+            w, b = p[name + ".weight"], p[name + ".bias"]
+            if kind == "batch" and norm is not None:
+                w, b = _fold_bn(w, b, p, norm)
+            return w, b, kw
+
+        w, b, _ = conv("conv1", "norm1")
+        # 7x7 s2 on 3 channels -> im2col (k = (ky,kx,c)) + GEMM
+        self.c1_kpad = ops.pad32(147)
+        self.conv1 = ops.make_conv_spec(w.permute(0, 2, 3, 1).reshape(64, 147, 1, 1), b, dt, seg_channels=[self.c1_kpad],
+                                        seg_valid=[147]).to(device)
+        self.blocks = []
+        cin = 64
+        for layer, dim, stride in (("layer1", 64, 1), ("layer2", 96, 2), ("layer3", 128, 2)):
+            for bi, st in ((0, stride), (1, 1)):
+                pre = f"{layer}.{bi}."
+                w1, b1, _ = conv(pre + "conv1", pre + "norm1")
+                w2, b2, _ = conv(pre + "conv2", pre + "norm2")
+                blk = {
+                    "c1": ops.make_conv_spec(w1, b1, dt, stride=st, padding=1).to(device),
+                    "c2": ops.make_conv_spec(w2, b2, dt, padding=1).to(device),
+                    "down": None, "dim": dim, "stride": st,
+                }
+                if st != 1:
+                    wd, bd, _ = conv(pre + "downsample.0", pre + "norm3")
+                    blk["down"] = ops.make_conv_spec(wd, bd, dt, stride=st).to(device)
+                self.blocks.append(blk)
+                cin = dim
+        self.conv2 = ops.make_conv_spec(p["conv2.weight"], p["conv2.bias"], dt).to(device)
+
+    def __call__(self, frames: torch.Tensor, out: torch.Tensor, *, split_tanh_relu: bool) -> torch.Tensor:
+        """frames [n,H,W,3] fp32 -> out [n,H/8,W/8,256]."""
+        dev = frames.device
+        n, H, W, _ = frames.shape
+        inst = self.kind == "instance"
+        h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        cols = torch.empty(n, h2, w2, self.c1_kpad, device=dev)
+        ops.im2col(frames, cols, 7, 7, stride=2, padding=3)
+        x = torch.empty(n, h2, w2, 64, device=dev)
+        if inst:
+            ops.conv2d(self.conv1, [cols], x)
+            ops.instnorm(x, x, relu_pre=True)
+        else:
+            ops.conv2d(self.conv1, [cols], x, act="relu")
+        del cols
+        for blk in self.blocks:
+            _, h, w, _ = x.shape
+            ho, wo = blk["c1"].out_hw(h, w)
+            y1 = torch.empty(n, ho, wo, blk["dim"], device=dev)
+            y2 = torch.empty(n, ho, wo, blk["dim"], device=dev)
+            if inst:
+                ops.conv2d(blk["c1"], [x], y1)
+                ops.instnorm(y1, y1, relu_pre=True)
+                ops.conv2d(blk["c2"], [y1], y2)
+                skip = x
+                if blk["down"] is not None:
+                    skip = torch.empty(n, ho, wo, blk["dim"], device=dev)
+                    ops.conv2d(blk["down"], [x], skip)
+                    ops.instnorm(skip, skip)
+                ops.instnorm(y2, y2, relu_pre=True, skip=skip, relu_post=True)
+            else:
+                ops.conv2d(blk["c1"], [x], y1, act="relu")
+                skip = x
+                if blk["down"] is not None:
+                    skip = torch.empty(n, ho, wo, blk["dim"], device=dev)
+                    ops.conv2d(blk["down"], [x], skip)
+                ops.conv2d(blk["c2"], [y1], y2, act="relu", epi="add_relu", aux1=skip)
+            x = y2
+        if split_tanh_relu:  # raft.py:119-122: net = tanh(c[:128]), inp = relu(c[128:])
+            ops.conv2d(self.conv2, [x], out, act="tanh", act2="relu", act_split=128)
+        else:
+            ops.conv2d(self.conv2, [x], out)
+        return out
+
+
+class RaftFlow:
+    def __init__(self, sd: dict, device, *, max_volume_bytes: int = 48 << 30, enc_chunk: int = 16):
+        self.device = torch.device(device)
+        self.max_volume_bytes = max_volume_bytes
+        self.enc_chunk = enc_chunk
+        dt = torch.float32
+        self.fnet = _Encoder(_strip(sd, "fnet."), "instance", device)
+        self.cnet = _Encoder(_strip(sd, "cnet."), "batch", device)
+        u = _strip(sd, "update_block.")
+
+        def spec(name, **kw):
+            return ops.make_conv_spec(u[name + ".weight"], u[name + ".bias"], dt, **kw).to(device)
+
+        self.convc1 = spec("encoder.convc1")
+        self.convc2 = spec("encoder.convc2", padding=1)
+        wf1 = u["encoder.convf1.weight"]  # [128,2,7,7] -> im2col GEMM
+        self.f1_kpad = ops.pad32(98)
+        self.convf1 = ops.make_conv_spec(wf1.permute(0, 2, 3, 1).reshape(128, 98, 1, 1), u["encoder.convf1.bias"], dt,
+                                         seg_channels=[self.f1_kpad], seg_valid=[98]).to(device)
+        self.convf2 = spec("encoder.convf2", padding=1)
+        self.conv = spec("encoder.conv", padding=1)
+        # GRU input = cat(h, inp, motion) as three K segments (update.py:60-71)
+        seg = [128, 128, 128]
+        self.gru = {}
+        for g in "zrq":
+            self.gru[g + "1"] = spec(f"gru.conv{g}1", padding=(0, 2), seg_channels=seg)
+            self.gru[g + "2"] = spec(f"gru.conv{g}2", padding=(2, 0), seg_channels=seg)
+        self.fh1 = spec("flow_head.conv1", padding=1)
+        self.fh2 = spec("flow_head.conv2", padding=1)
+        self.mask0 = spec("mask.0", padding=1)
+        self.mask2 = spec("mask.2")
+
+    # ------------------------------------------------------------------------------------
+    def encode(self, frames: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """frames [T,H,W,3] fp32 in [-1,1] -> (fmap [T,h8,w8,256], ctx [T,h8,w8,256] = tanh|relu)."""
+        T, H, W, _ = frames.shape
+        h8, w8 = H // 8, W // 8
+        fmap = torch.empty(T, h8, w8, 256, device=frames.device)
+        ctx = torch.empty(T, h8, w8, 256, device=frames.device)
+        for s in range(0, T, self.enc_chunk):
+            e = min(T, s + self.enc_chunk)
+            self.fnet(frames[s:e], fmap[s:e], split_tanh_relu=False)
+            self.cnet(frames[s:e], ctx[s:e], split_tanh_relu=True)
+        return fmap, ctx
+
+    def _update_pairs(self, f1, f2, ctx, iters: int, flow_up: torch.Tensor, trace: dict | None = None) -> None:
+        """One batch of pair-directions: f1,f2 [P,hw,256], ctx [P,h,w,256] -> flow_up [P,8h,8w,2]."""
+        dev = f1.device
+        P, h, w, _ = ctx.shape
+        hw = h * w
+        vol = torch.empty(P, 1, hw, hw, device=dev)
+        ops.batched_gemm_nt(f1.view(P, 1, hw, 256), f2, vol, scale=1.0 / 16.0)  # corr.py:52-60 (/sqrt(256))
+        pyr = [vol.view(P, hw, h, w)]
+        for _ in range(3):
+            ph, pw = pyr[-1].shape[2] // 2, pyr[-1].shape[3] // 2
+            nxt = torch.empty(P, hw, ph, pw, device=dev)
+            ops.avgpool2x2(pyr[-1].view(P * hw, pyr[-1].shape[2], pyr[-1].shape[3]), nxt.view(P * hw, ph, pw))
+            pyr.append(nxt)
+        corr = torch.empty(P, h, w, 324, device=dev)
+        cor1 = torch.empty(P, h, w, 256, device=dev)
+        cf = torch.empty(P, h, w, 256, device=dev)       # cor (192) | flo (64)
+        fcols = torch.empty(P, h, w, self.f1_kpad, device=dev)
+        flo1 = torch.empty(P, h, w, 128, device=dev)
+        mf = torch.zeros(P, h, w, 128, device=dev)       # motion (126) | flow (2)
+        flow = mf[..., 126:128]
+        inp = ctx[..., 128:256]
+        hcur = ctx[..., 0:128]
+        hA = torch.empty(P, h, w, 128, device=dev)
+        hB = torch.empty(P, h, w, 128, device=dev)
+        z = torch.empty(P, h, w, 128, device=dev)
+        rh = torch.empty(P, h, w, 128, device=dev)
+        t256 = torch.empty(P, h, w, 256, device=dev)
+        for it in range(iters):
+            ops.corr_lookup(pyr, flow, corr)
+            if trace is not None and it == 0:
+                trace["corr0"] = corr.clone()
+            ops.conv2d(self.convc1, [corr], cor1, act="relu")
+            ops.conv2d(self.convc2, [cor1], cf[..., 0:192], act="relu")
+            ops.im2col(flow, fcols, 7, 7, padding=3)
+            ops.conv2d(self.convf1, [fcols], flo1, act="relu")
+            ops.conv2d(self.convf2, [flo1], cf[..., 192:256], act="relu")
+            ops.conv2d(self.conv, [cf], mf[..., 0:126], act="relu")
+            for sfx, hout in (("1", hA), ("2", hB)):
+                segs = [hcur, inp, mf]
+                ops.conv2d(self.gru["z" + sfx], segs, z, act="sigmoid")
+                ops.conv2d(self.gru["r" + sfx], segs, rh, act="sigmoid", epi="mul", aux1=hcur)
+                ops.conv2d(self.gru["q" + sfx], [rh, inp, mf], hout, act="tanh", epi="gru", aux1=z, aux2=hcur)
+                hcur = hout
+            ops.conv2d(self.fh1, [hcur], t256, act="relu")
+            ops.conv2d(self.fh2, [t256], flow, epi="add", aux1=flow)  # coords1 += delta (raft.py:139)
+        ops.conv2d(self.mask0, [hcur], t256, act="relu")
+        mask = torch.empty(P, h, w, 576, device=dev)
+        ops.conv2d(self.mask2, [t256], mask, out_scale=0.25)           # update.py:153
+        ops.convex_upsample(mask, flow, flow_up)
+        if trace is not None:
+            trace.update(flow_lr=flow.clone(), net=hcur.clone(), mask=mask)
+
+    def __call__(self, frames: torch.Tensor, iters: int, trace: dict | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """frames [T,H,W,3] fp32 in [-1,1] (channels-last) -> (flows_fwd, flows_bwd), each [T-1,H,W,2]."""
+        T, H, W, _ = frames.shape
+        if H % 8 or W % 8 or H < 128 or W < 128:
+            raise ValueError("RAFT needs H, W multiples of 8 and >= 128 (reference limit, SURVEY.md 9.15)")
+        fmap, ctx = self.encode(frames)
+        if trace is not None:
+            trace.update(fmap=fmap, ctx=ctx)
+        h, w = H // 8, W // 8
+        hw = h * w
+        fm = fmap.view(T, hw, 256)
+        npair = T - 1
+        out = torch.empty(2, npair, H, W, 2, device=frames.device)
+        per_pair = int(hw * hw * 4 * 1.34) + hw * 4 * 3000
+        chunk = max(1, min(npair, self.max_volume_bytes // (2 * per_pair)))
+        for s in range(0, npair, chunk):
+            e = min(npair, s + chunk)
+            n = e - s
+            # forward pairs (i -> i+1) then backward pairs (i+1 -> i) in ONE batch of 2n
+            f1 = torch.cat([fm[s:e], fm[s + 1:e + 1]], 0)
+            f2 = torch.cat([fm[s + 1:e + 1], fm[s:e]], 0)
+            cx = torch.cat([ctx[s:e], ctx[s + 1:e + 1]], 0)
+            up = torch.empty(2 * n, H, W, 2, device=frames.device)
+            self._update_pairs(f1, f2, cx, iters, up, trace)
+            out[0, s:e] = up[:n]
+            out[1, s:e] = up[n:]
+        return out[0], out[1]

@@ -111,6 +111,93 @@ typedef struct {
 
 int32_t pp_conv2d(void* stream, const pp_conv2d_params* p);
 
+/* ------------------------------------------------------------------------------------
+ * pp_im2col -- explicit patch matrix for the few convolutions whose Cin is too small for
+ * 16-byte channel pieces (RAFT extractor.py:135 conv1 3->64 k7 s2, update.py:100 convf1
+ * 2->128 k7, propainter.py:240 5->64 k3 s2, recurrent_flow_completion.py:240 3->32 k5 s2
+ * replicate).  out[m][k], m = (n,ho,wo), k = (ky*kw+kx)*C + c, zero-filled up to Kpad;
+ * the result feeds pp_conv2d as a 1x1 convolution.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;     /* input dtype */
+  int32_t out_dtype;
+  int32_t pad_mode;
+  int32_t kh, kw, sh, sw, ph, pw;
+  const void* in;
+  int64_t in_ldc;
+  int64_t N, H, W, C, Ho, Wo;
+  void* out;
+  int64_t Kpad;
+} pp_im2col_params;
+int32_t pp_im2col(void* stream, const pp_im2col_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_instnorm -- torch.nn.InstanceNorm2d(affine=False, eps=1e-5) of RAFT's fnet
+ * (extractor.py:32-36,134-135, forward :44-57,181-183) on channels-last fp32, fused with
+ * the surrounding ReLU / residual: y = post( skip + pre( (x-mean)*rstd ) ).
+ * `partials` is caller-owned scratch of N*nchunks*C*2 doubles.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;
+  int64_t x_ldc;
+  void* y;
+  int64_t y_ldc;
+  const void* skip; /* optional residual input (same shape), NULL = none */
+  int64_t skip_ldc;
+  int64_t N, HW, C;
+  int32_t relu_pre;
+  int32_t relu_post;
+  void* partials;
+  int64_t nchunks;
+  float eps;
+} pp_instnorm_params;
+int32_t pp_instnorm(void* stream, const pp_instnorm_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_avgpool2x2 -- F.avg_pool2d(corr, 2, stride=2) over a batch of fp32 planes
+ * (corr.py:24-27): in [B][H][W] -> out [B][H/2][W/2] (floor).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* in;
+  void* out;
+  int64_t B, H, W;
+} pp_avgpool2x2_params;
+int32_t pp_avgpool2x2(void* stream, const pp_avgpool2x2_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_corr_lookup -- CorrBlock.__call__ (corr.py:29-50) + bilinear_sampler
+ * (RAFT/utils/utils.py:66-80): for every pixel of every pair, sample a 9x9 window around
+ * (grid + flow)/2^l in each of the 4 pyramid levels (bilinear, zeros outside,
+ * align_corners=True).  out[n][y][x][l*81 + i*9 + j], i offsets X, j offsets Y.
+ * pyramid level l: fp32 [N][h*w][h_l][w_l]; flow: channels-last (dx,dy) with pitch flow_ldc.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* pyr[4];
+  int64_t ph[4];
+  int64_t pw[4];
+  const void* flow;
+  int64_t flow_ldc;
+  void* out;
+  int64_t out_ldc;
+  int64_t N, h, w;
+} pp_corr_lookup_params;
+int32_t pp_corr_lookup(void* stream, const pp_corr_lookup_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_convex_upsample -- RAFT.upsample_flow (raft.py:81-92): softmax over the 9 taps of
+ * mask[n][y][x][k*64 + a*8 + b], convex combination of 8*flow over the 3x3 neighbourhood
+ * (zero padded).  out: channels-last [N][8h][8w][2] fp32.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* mask;
+  int64_t mask_ldc;
+  const void* flow;
+  int64_t flow_ldc;
+  void* out;
+  int64_t N, h, w;
+} pp_convex_upsample_params;
+int32_t pp_convex_upsample(void* stream, const pp_convex_upsample_params* p);
+
 #ifdef __cplusplus
 }
 #endif

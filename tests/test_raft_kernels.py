@@ -1,0 +1,75 @@
+"""RAFT-stage gather/normalisation kernels against the oracle's torch formulation (fp32, atol 2e-5)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from comfyui_propainter_nodes_amd import ops
+from oracle import raft as OR
+
+
+def test_im2col_matches_unfold(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 11, 13, 3, generator=g)
+    out = torch.empty(2, 6, 7, 160, device=dev)
+    ops.im2col(x.to(dev), out, 7, 7, stride=2, padding=3)
+    ref = F.unfold(x.permute(0, 3, 1, 2), 7, padding=3, stride=2)  # [n, c*49, L] with (c,ky,kx) order
+    ref = ref.view(2, 3, 49, 6, 7).permute(0, 3, 4, 2, 1).reshape(2, 6, 7, 147)
+    assert torch.equal(out.cpu()[..., :147], ref)
+    assert torch.all(out.cpu()[..., 147:] == 0)
+    # replicate padding + channel-slice input (flow stored inside a wider buffer)
+    buf = torch.randn(1, 9, 10, 8, generator=g)
+    out2 = torch.empty(1, 5, 5, 96, device=dev)
+    ops.im2col(buf.to(dev)[..., 5:8], out2, 5, 5, stride=2, padding=2, pad_mode="replicate")
+    xp = F.pad(buf[..., 5:8].permute(0, 3, 1, 2), (2, 2, 2, 2), mode="replicate")
+    ref2 = F.unfold(xp, 5, stride=2).view(1, 3, 25, 5, 5).permute(0, 3, 4, 2, 1).reshape(1, 5, 5, 75)
+    assert torch.equal(out2.cpu()[..., :75], ref2)
+
+
+@pytest.mark.parametrize("C", [64, 96, 128])
+def test_instnorm(backend, C):
+    dev = backend
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 24, 31, C, generator=g) * 3 + 1.5
+    skip = torch.randn(2, 24, 31, C, generator=g)
+    ref = F.instance_norm(x.permute(0, 3, 1, 2), eps=1e-5).permute(0, 2, 3, 1)
+    y = torch.empty_like(x, device=dev)
+    ops.instnorm(x.to(dev), y, relu_pre=True)
+    assert torch.allclose(y.cpu(), F.relu(ref), atol=2e-5)
+    ops.instnorm(x.to(dev), y, relu_pre=True, skip=skip.to(dev), relu_post=True)
+    assert torch.allclose(y.cpu(), F.relu(skip + F.relu(ref)), atol=2e-5)
+    xin = x.to(dev)
+    ops.instnorm(xin, xin)  # in place, no relu
+    assert torch.allclose(xin.cpu(), ref, atol=2e-5)
+
+
+def test_pyramid_lookup_upsample(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 2, 16, 18
+    f1 = torch.randn(n, 32, h, w, generator=g)
+    f2 = torch.randn(n, 32, h, w, generator=g)
+    pyr_ref = OR.corr_pyramid(f1, f2)
+    vol = pyr_ref[0].view(n, h * w, h, w).contiguous().to(dev)
+    pyr = [vol]
+    for lvl in range(3):
+        ph, pw = pyr[-1].shape[2] // 2, pyr[-1].shape[3] // 2
+        nxt = torch.empty(n, h * w, ph, pw, device=dev)
+        ops.avgpool2x2(pyr[-1].view(n * h * w, *pyr[-1].shape[2:]), nxt.view(n * h * w, ph, pw))
+        assert torch.allclose(nxt.cpu().view(-1, 1, ph, pw), pyr_ref[lvl + 1], atol=1e-6)
+        pyr.append(nxt)
+    # flows large enough to leave the image on some pixels (zero padding path)
+    flow = torch.randn(n, h, w, 2, generator=g) * 6
+    buf = torch.zeros(n, h, w, 8, device=dev)
+    buf[..., 6:8] = flow.to(dev)
+    out = torch.empty(n, h, w, 324, device=dev)
+    ops.corr_lookup(pyr, buf[..., 6:8], out)
+    coords = OR.coords_grid(n, h, w) + flow.permute(0, 3, 1, 2)
+    ref = OR.corr_lookup(pyr_ref, coords).permute(0, 2, 3, 1)
+    assert torch.allclose(out.cpu(), ref, atol=2e-5)
+    # convex upsampling
+    mask = torch.randn(n, h, w, 576, generator=g)
+    up = torch.empty(n, 8 * h, 8 * w, 2, device=dev)
+    ops.convex_upsample(mask.to(dev), buf[..., 6:8], up)
+    ref_up = OR.convex_upsample(flow.permute(0, 3, 1, 2), mask.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert torch.allclose(up.cpu(), ref_up, atol=2e-5 * ref_up.abs().max().item())
