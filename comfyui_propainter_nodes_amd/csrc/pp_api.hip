@@ -52,5 +52,9 @@ extern "C" int64_t pp_struct_size(const char* name) {
   PP_SIZEOF_CASE(pp_avgpool2x2_params)
   PP_SIZEOF_CASE(pp_corr_lookup_params)
   PP_SIZEOF_CASE(pp_convex_upsample_params)
+  PP_SIZEOF_CASE(pp_deform_cols_params)
+  PP_SIZEOF_CASE(pp_upsample2x_params)
+  PP_SIZEOF_CASE(pp_rfc_prep_params)
+  PP_SIZEOF_CASE(pp_flow_combine_params)
   return -1;
 }

@@ -1,0 +1,218 @@
+// sample_kernels.hip -- bandwidth-bound sampling kernels shared by the flow-completion and
+// inpainting stages: deformable-conv column sampling, bilinear 2x upsampling, and the
+// flow-completion input/output elementwise passes.  Contracts: include/propainter_mi355.h.
+#include "pp_device.h"
+#include "pp_host.h"
+
+namespace pp {
+
+static inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+// ----------------------------------------------------------------------------------------
+// deformable-conv column sampling: one thread per (pixel, tap k, deformable group g)
+// ----------------------------------------------------------------------------------------
+struct DeformK {
+  const void* x0;
+  int x0_C, x0_ldc;
+  const void* x1;
+  int x1_C, x1_ldc;
+  const float* om;
+  int om_ldc;
+  const float* flow;
+  int flow_ldc;
+  void* cols;
+  int H, W, dg, cg, Cin;
+  int64_t total;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) deform_cols_kernel(const DeformK k) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= k.total) return;
+  const int g = (int)(idx % k.dg);
+  const int64_t t = idx / k.dg;
+  const int tap = (int)(t % 9);
+  const int64_t pix = t / 9;
+  const int hw = k.H * k.W;
+  const int p = (int)(pix % hw);
+  const int64_t n = pix / hw;
+  const int y = p / k.W, x = p - y * k.W;
+  const float* om = k.om + pix * k.om_ldc;
+  float dy = om[g * 18 + 2 * tap];
+  float dx = om[g * 18 + 2 * tap + 1];
+  const float m = om[k.dg * 18 + g * 9 + tap];
+  if (k.flow) {
+    const float* f = k.flow + pix * k.flow_ldc;
+    dx += f[0];
+    dy += f[1];
+  }
+  const float py = (float)(y - 1 + tap / 3) + dy;
+  const float px = (float)(x - 1 + tap % 3) + dx;
+  T* dst = reinterpret_cast<T*>(k.cols) + pix * (int64_t)(9 * k.Cin) + tap * k.Cin + g * k.cg;
+  // source slab of this group's channels
+  const int c0 = g * k.cg;
+  const T* src;
+  int ldc;
+  if (c0 < k.x0_C) {
+    src = reinterpret_cast<const T*>(k.x0) + c0;
+    ldc = k.x0_ldc;
+  } else {
+    src = reinterpret_cast<const T*>(k.x1) + (c0 - k.x0_C);
+    ldc = k.x1_ldc;
+  }
+  src += n * (int64_t)hw * ldc;
+  const bool inside = (py > -1.f) && (py < (float)k.H) && (px > -1.f) && (px < (float)k.W);
+  const float fy = floorf(py), fx = floorf(px);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const float ly = py - fy, lx = px - fx;
+  const float w00 = (1.f - ly) * (1.f - lx) * m, w01 = (1.f - ly) * lx * m;
+  const float w10 = ly * (1.f - lx) * m, w11 = ly * lx * m;
+  const bool y0ok = inside && y0 >= 0, y1ok = inside && (y0 + 1 <= k.H - 1);
+  const bool x0ok = x0 >= 0, x1ok = (x0 + 1 <= k.W - 1);
+  const T* r00 = src + ((int64_t)y0 * k.W + x0) * ldc;
+  const T* r01 = r00 + ldc;
+  const T* r10 = r00 + (int64_t)k.W * ldc;
+  const T* r11 = r10 + ldc;
+  for (int c = 0; c < k.cg; ++c) {
+    float v = 0.f;
+    if (y0ok && x0ok) v += w00 * to_f32(r00[c]);
+    if (y0ok && x1ok) v += w01 * to_f32(r01[c]);
+    if (y1ok && x0ok) v += w10 * to_f32(r10[c]);
+    if (y1ok && x1ok) v += w11 * to_f32(r11[c]);
+    dst[c] = from_f32<T>(v);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// bilinear 2x upsampling, align_corners=True (one thread per output pixel x 8-channel piece)
+// ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ in, int in_ldc, T* __restrict__ out,
+                                                         int out_ldc, int H, int W, int C, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const int64_t opix = idx / C;
+  const int Wo = 2 * W, Ho = 2 * H;
+  const int xo = (int)(opix % Wo);
+  const int64_t t = opix / Wo;
+  const int yo = (int)(t % Ho);
+  const int64_t n = t / Ho;
+  const float sy = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const float fy = sy * (float)yo, fx = sx * (float)xo;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const T* base = in + n * (int64_t)H * W * in_ldc + c;
+  const float v00 = to_f32(base[((int64_t)y0 * W + x0) * in_ldc]);
+  const float v01 = to_f32(base[((int64_t)y0 * W + x1) * in_ldc]);
+  const float v10 = to_f32(base[((int64_t)y1 * W + x0) * in_ldc]);
+  const float v11 = to_f32(base[((int64_t)y1 * W + x1) * in_ldc]);
+  const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  out[opix * out_ldc + c] = from_f32<T>(v);
+}
+
+// ----------------------------------------------------------------------------------------
+// flow-completion input / output passes
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rfc_prep_kernel(const float* __restrict__ flows,
+                                                       const unsigned char* __restrict__ masks,
+                                                       half_t* __restrict__ out, int T, int64_t HW, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [2][T][HW]
+  if (idx >= total) return;
+  const int64_t p = idx % HW;
+  const int64_t r = idx / HW;
+  const int t = (int)(r % T);
+  const int d = (int)(r / T);
+  const float m = masks[(int64_t)(t + d) * HW + p] ? 1.f : 0.f;
+  const float* f = flows + idx * 2;
+  const int to = d ? (T - 1 - t) : t;
+  half_t* o = out + (((int64_t)to * 2 + d) * HW + p) * 4;
+  h4 v = {(half_t)(f[0] * (1.f - m)), (half_t)(f[1] * (1.f - m)), (half_t)m, (half_t)0.f};
+  *reinterpret_cast<h4*>(o) = v;
+}
+
+__global__ void __launch_bounds__(256) flow_combine_kernel(const half_t* __restrict__ pred, int pred_ldc,
+                                                           const float* __restrict__ flows,
+                                                           const unsigned char* __restrict__ masks,
+                                                           float* __restrict__ out, int T, int64_t HW, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [2][T][HW]
+  if (idx >= total) return;
+  const int64_t p = idx % HW;
+  const int64_t r = idx / HW;
+  const int t = (int)(r % T);
+  const int d = (int)(r / T);
+  const float m = masks[(int64_t)(t + d) * HW + p] ? 1.f : 0.f;
+  const int tp = d ? (T - 1 - t) : t;
+  const half_t* pr = pred + (((int64_t)tp * 2 + d) * HW + p) * pred_ldc;
+  const float* f = flows + idx * 2;
+  out[idx * 2 + 0] = (float)pr[0] * m + f[0] * (1.f - m);
+  out[idx * 2 + 1] = (float)pr[1] * m + f[1] * (1.f - m);
+}
+
+}  // namespace pp
+
+extern "C" int32_t pp_deform_cols(void* stream, const pp_deform_cols_params* p) {
+  using namespace pp;
+  if (!p || !p->x0 || !p->om || !p->cols) return pp_fail(PP_ERR_BAD_ARG, "pp_deform_cols: null argument");
+  if (p->dtype != PP_F16 && p->dtype != PP_F32) return pp_fail(PP_ERR_UNSUPPORTED, "pp_deform_cols: dtype");
+  DeformK k;
+  k.x0 = p->x0; k.x0_C = (int)p->x0_C; k.x0_ldc = (int)p->x0_ldc;
+  k.x1 = p->x1; k.x1_C = p->x1 ? (int)p->x1_C : 0; k.x1_ldc = (int)p->x1_ldc;
+  k.om = (const float*)p->om; k.om_ldc = (int)p->om_ldc;
+  k.flow = (const float*)p->flow; k.flow_ldc = (int)p->flow_ldc;
+  k.cols = p->cols;
+  k.H = (int)p->H; k.W = (int)p->W; k.dg = p->dg;
+  k.Cin = k.x0_C + k.x1_C;
+  if (k.dg < 1 || k.Cin % k.dg != 0) return pp_fail(PP_ERR_BAD_ARG, "pp_deform_cols: channels not divisible by dg");
+  k.cg = k.Cin / k.dg;
+  if (k.x0_C % k.cg != 0) return pp_fail(PP_ERR_BAD_ARG, "pp_deform_cols: a deformable group straddles the two inputs");
+  k.total = p->N * p->H * p->W * 9 * k.dg;
+  if (k.total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_deform_cols: empty problem");
+  if (p->dtype == PP_F16) {
+    PP_LAUNCH((deform_cols_kernel<half_t>), dim3(nblk(k.total)), dim3(256), 0, stream, k);
+  } else {
+    PP_LAUNCH((deform_cols_kernel<float>), dim3(nblk(k.total)), dim3(256), 0, stream, k);
+  }
+  return pp_check_launch("pp_deform_cols");
+}
+
+extern "C" int32_t pp_upsample2x(void* stream, const pp_upsample2x_params* p) {
+  using namespace pp;
+  if (!p || !p->in || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_upsample2x: null argument");
+  const int64_t total = p->N * 4 * p->H * p->W * p->C;
+  if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_upsample2x: empty problem");
+  if (p->dtype == PP_F16) {
+    PP_LAUNCH((upsample2x_kernel<half_t>), dim3(nblk(total)), dim3(256), 0, stream, (const half_t*)p->in,
+              (int)p->in_ldc, (half_t*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, total);
+  } else if (p->dtype == PP_F32) {
+    PP_LAUNCH((upsample2x_kernel<float>), dim3(nblk(total)), dim3(256), 0, stream, (const float*)p->in,
+              (int)p->in_ldc, (float*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, total);
+  } else {
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_upsample2x: dtype");
+  }
+  return pp_check_launch("pp_upsample2x");
+}
+
+extern "C" int32_t pp_rfc_prep(void* stream, const pp_rfc_prep_params* p) {
+  using namespace pp;
+  if (!p || !p->flows || !p->masks || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_rfc_prep: null argument");
+  const int64_t HW = p->H * p->W;
+  const int64_t total = 2 * p->T * HW;
+  if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_rfc_prep: empty problem");
+  PP_LAUNCH(rfc_prep_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const float*)p->flows,
+            (const unsigned char*)p->masks, (half_t*)p->out, (int)p->T, HW, total);
+  return pp_check_launch("pp_rfc_prep");
+}
+
+extern "C" int32_t pp_flow_combine(void* stream, const pp_flow_combine_params* p) {
+  using namespace pp;
+  if (!p || !p->pred || !p->flows || !p->masks || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_flow_combine: null argument");
+  const int64_t HW = p->H * p->W;
+  const int64_t total = 2 * p->T * HW;
+  if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_flow_combine: empty problem");
+  PP_LAUNCH(flow_combine_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const half_t*)p->pred, (int)p->pred_ldc,
+            (const float*)p->flows, (const unsigned char*)p->masks, (float*)p->out, (int)p->T, HW, total);
+  return pp_check_launch("pp_flow_combine");
+}

@@ -351,3 +351,74 @@ def convex_upsample(mask: torch.Tensor, flow: torch.Tensor, out: torch.Tensor) -
     P.out, P.N, P.h, P.w = out.data_ptr(), n, h, w
     _call("pp_convex_upsample", out, P)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# sampling kernels
+# --------------------------------------------------------------------------------------------
+def deform_cols(x0: torch.Tensor, x1: torch.Tensor | None, om: torch.Tensor, cols: torch.Tensor, *, dg: int = 16,
+                flow: torch.Tensor | None = None) -> torch.Tensor:
+    """Sampling half of the modulated deformable 3x3 conv: cols [N,H,W,9*Cin] (tap-major)."""
+    check_device(x0, x1, om, cols, flow)
+    n, h, w, c0, l0 = nhwc_view(x0)
+    P = _lib.STRUCTS["pp_deform_cols_params"]()
+    P.dtype, P.dg = dtype_code(x0.dtype), dg
+    P.x0, P.x0_C, P.x0_ldc = x0.data_ptr(), c0, l0
+    c1 = 0
+    if x1 is not None:
+        _, _, _, c1, l1 = nhwc_view(x1)
+        P.x1, P.x1_C, P.x1_ldc = x1.data_ptr(), c1, l1
+    if om.dtype != torch.float32 or om.shape[3] != 27 * dg:
+        raise ValueError("deform_cols: om must be fp32 with 27*dg channels")
+    P.om, P.om_ldc = om.data_ptr(), nhwc_view(om)[4]
+    if flow is not None:
+        if flow.dtype != torch.float32:
+            raise TypeError("deform_cols: flow must be fp32")
+        P.flow, P.flow_ldc = flow.data_ptr(), nhwc_view(flow)[4]
+    if cols.dtype != x0.dtype or not cols.is_contiguous() or tuple(cols.shape) != (n, h, w, 9 * (c0 + c1)):
+        raise ValueError("deform_cols: bad cols tensor")
+    P.cols, P.N, P.H, P.W = cols.data_ptr(), n, h, w
+    _call("pp_deform_cols", cols, P)
+    return cols
+
+
+def upsample2x(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    check_device(x, out)
+    n, h, w, c, ldc = nhwc_view(x)
+    on, oh, ow, oc, oldc = nhwc_view(out)
+    if (on, oh, ow, oc) != (n, 2 * h, 2 * w, c) or out.dtype != x.dtype:
+        raise ValueError("upsample2x: bad output")
+    P = _lib.STRUCTS["pp_upsample2x_params"]()
+    P.dtype = dtype_code(x.dtype)
+    setattr(P, "in", x.data_ptr())
+    P.in_ldc, P.out, P.out_ldc = ldc, out.data_ptr(), oldc
+    P.N, P.H, P.W, P.C = n, h, w, c
+    _call("pp_upsample2x", out, P)
+    return out
+
+
+def rfc_prep(flows: torch.Tensor, masks_u8: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """flows fp32 [2,T,H,W,2], masks u8 [T+1,H,W] -> out f16 [T,2,H,W,4] (direction 1 time-flipped)."""
+    check_device(flows, masks_u8, out)
+    _, t, h, w, _ = flows.shape
+    if not (flows.is_contiguous() and masks_u8.is_contiguous() and out.is_contiguous()):
+        raise ValueError("rfc_prep: tensors must be dense")
+    if masks_u8.dtype != torch.uint8 or tuple(masks_u8.shape) != (t + 1, h, w) or tuple(out.shape) != (t, 2, h, w, 4):
+        raise ValueError("rfc_prep: bad shapes")
+    P = _lib.STRUCTS["pp_rfc_prep_params"]()
+    P.flows, P.masks, P.out, P.T, P.H, P.W = flows.data_ptr(), masks_u8.data_ptr(), out.data_ptr(), t, h, w
+    _call("pp_rfc_prep", out, P)
+    return out
+
+
+def flow_combine(pred: torch.Tensor, flows: torch.Tensor, masks_u8: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """pred f16 [T,2,H,W,>=2] (direction 1 time-flipped) + gt flows fp32 [2,T,H,W,2] -> out fp32 [2,T,H,W,2]."""
+    check_device(pred, flows, masks_u8, out)
+    _, t, h, w, _ = flows.shape
+    if pred.dtype != torch.float16 or tuple(pred.shape[:4]) != (t, 2, h, w):
+        raise ValueError("flow_combine: bad pred")
+    P = _lib.STRUCTS["pp_flow_combine_params"]()
+    P.pred, P.pred_ldc = pred.data_ptr(), pred.stride(3)
+    P.flows, P.masks, P.out, P.T, P.H, P.W = flows.data_ptr(), masks_u8.data_ptr(), out.data_ptr(), t, h, w
+    _call("pp_flow_combine", out, P)
+    return out

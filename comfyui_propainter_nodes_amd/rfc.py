@@ -1,0 +1,172 @@
+"""Recurrent flow completion on the MI355X (fp16 activations / fp32 accumulate, like the reference
+runs this net `.half()`: utils/model_utils.py:55-58).
+
+Replaces RecurrentFlowCompleteNet.forward_bidirect_flow + combine_flow
+(model/recurrent_flow_completion.py:315-400).  Scheduling decisions:
+
+  * the forward-flow and the (time-flipped) backward-flow applications share weights, so they
+    run as ONE batch of 2 through every kernel, laid out [T][2][h][w][C] so that each step of
+    the second-order recurrence (:96-131) is a dense batch of 2 images;
+  * Conv3d(1,k,k) layers are 2-D convolutions over the T*2 images, Conv3d(3,1,1,dilation 2)
+    layers are 2-D convolutions over a [T] x [2*h*w] "image" (kernel 3x1) -- same MFMA kernel;
+  * every torch.cat is a K-segment list, the deformable conv is sampling (pp_deform_cols) +
+    the same GEMM kernel, residual adds and activations are conv epilogues.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+F16 = torch.float16
+
+
+class FlowCompleter:
+    def __init__(self, sd: dict, device):
+        self.device = torch.device(device)
+        p = {k: v.float() for k, v in sd.items() if not k.startswith("edgeDetector")}
+
+        def c2(name, **kw):  # Conv3d (1,k,k) or Conv2d
+            w = p[name + ".weight"]
+            if w.dim() == 5:
+                w = w[:, :, 0]
+            return ops.make_conv_spec(w, p[name + ".bias"], F16, **kw).to(device)
+
+        def ct(name):  # Conv3d (3,1,1), dilation 2, padding 2 -> kernel 3x1 over [T] x [pixels]
+            w = p[name + ".weight"][:, :, :, 0, 0].unsqueeze(-1)  # [Co,Ci,3,1]
+            return ops.make_conv_spec(w, p[name + ".bias"], F16, padding=(2, 0), dilation=(2, 1)).to(device)
+
+        wd = p["downsample.0.weight"][:, :, 0]  # [32,3,5,5] -> im2col GEMM (replicate padding)
+        self.down_kpad = ops.pad32(75)
+        self.down = ops.make_conv_spec(wd.permute(0, 2, 3, 1).reshape(32, 75, 1, 1), p["downsample.0.bias"], F16,
+                                       seg_channels=[self.down_kpad], seg_valid=[75]).to(device)
+        self.enc = [
+            (c2("encoder1.0.conv1.0", padding=1), ct("encoder1.0.conv2.0")),
+            (c2("encoder1.2.conv1.0", stride=2, padding=1), ct("encoder1.2.conv2.0")),
+            (c2("encoder2.0.conv1.0", padding=1), ct("encoder2.0.conv2.0")),
+            (c2("encoder2.2.conv1.0", stride=2, padding=1), ct("encoder2.2.conv2.0")),
+        ]
+        self.mid = [c2(f"mid_dilation.{i}", padding=d, dilation=d) for i, d in ((0, 3), (2, 2), (4, 1))]
+        fp = "feat_prop_module."
+        self.prop = {}
+        for name, nseg in (("backward_", 2), ("forward_", 3)):
+            da = f"{fp}deform_align.{name}."
+            wm = p[da + "weight"]  # [128,256,3,3] -> GEMM over the sampled columns (tap-major)
+            self.prop[name] = {
+                "off0": c2(da + "conv_offset.0", padding=1, seg_channels=[128, 128, 128]),
+                "off2": c2(da + "conv_offset.2", padding=1),
+                "off4": c2(da + "conv_offset.4", padding=1),
+                "off6": c2(da + "conv_offset.6", padding=1),
+                "dcn": ops.make_conv_spec(wm.permute(0, 2, 3, 1).reshape(128, 9 * 256, 1, 1), p[da + "bias"], F16).to(device),
+                "bb0": c2(f"{fp}backbone.{name}.0", padding=1, seg_channels=[128] * nseg),
+                "bb2": c2(f"{fp}backbone.{name}.2", padding=1),
+            }
+        self.fusion = c2(fp + "fusion", seg_channels=[128, 128])
+        self.dec2_0 = c2("decoder2.0", padding=1)
+        self.dec2_2 = c2("decoder2.2.conv", padding=1)
+        self.dec1_0 = c2("decoder1.0", padding=1)
+        self.dec1_2 = c2("decoder1.2.conv", padding=1)
+        self.up_0 = c2("upsample.0", padding=1)
+        self.up_2 = c2("upsample.2.conv", padding=1)
+
+    # ------------------------------------------------------------------------------------
+    def _encode(self, x: torch.Tensor):
+        """x f16 [T,2,H,W,4] -> (e1 [T*2,H/4,W/4,64], mid [T,2,H/8,W/8,128])."""
+        dev = x.device
+        T, B, H, W, _ = x.shape
+        n = T * B
+        h2, w2 = (H + 4 - 5) // 2 + 1, (W + 4 - 5) // 2 + 1
+        cols = torch.empty(n, h2, w2, self.down_kpad, device=dev, dtype=F16)
+        ops.im2col(x.view(n, H, W, 4)[..., 0:3], cols, 5, 5, stride=2, padding=2, pad_mode="replicate")
+        cur = torch.empty(n, h2, w2, 32, device=dev, dtype=F16)
+        ops.conv2d(self.down, [cols], cur, act="leaky", act_param=0.2)
+        del cols
+        e1 = None
+        for li, (sp, tp) in enumerate(self.enc):
+            _, h, w, _ = cur.shape
+            ho, wo = sp.out_hw(h, w)
+            a = torch.empty(n, ho, wo, sp.cout, device=dev, dtype=F16)
+            ops.conv2d(sp, [cur], a, act="leaky", act_param=0.2)
+            b = torch.empty(n, ho, wo, sp.cout, device=dev, dtype=F16)
+            # temporal conv: rows = T, columns = B*ho*wo pixels
+            ops.conv2d(tp, [a.view(1, T, B * ho * wo, sp.cout)], b.view(1, T, B * ho * wo, sp.cout), act="leaky",
+                       act_param=0.2)
+            cur = b
+            if li == 1:
+                e1 = b
+        for sp in self.mid:
+            nxt = torch.empty_like(cur)
+            ops.conv2d(sp, [cur], nxt, act="leaky", act_param=0.2)
+            cur = nxt
+        _, h8, w8, _ = cur.shape
+        return e1, cur.view(T, B, h8, w8, 128)
+
+    def _propagate(self, mid: torch.Tensor) -> torch.Tensor:
+        """BidirectionalPropagation.forward (:77-143) on mid [T,2,h,w,128] -> [T,2,h,w,128]."""
+        dev = mid.device
+        T, B, h, w, C = mid.shape
+        outs = {}
+        zeros = torch.zeros(B, h, w, C, device=dev, dtype=F16)
+        t128 = torch.empty(B, h, w, 128, device=dev, dtype=F16)
+        u128 = torch.empty(B, h, w, 128, device=dev, dtype=F16)
+        om = torch.empty(B, h, w, 432, device=dev, dtype=torch.float32)
+        cols = torch.empty(B, h, w, 9 * 256, device=dev, dtype=F16)
+        aligned = torch.empty(B, h, w, 128, device=dev, dtype=F16)
+        for name in ("backward_", "forward_"):
+            S = self.prop[name]
+            order = list(range(T - 1, -1, -1)) if name == "backward_" else list(range(T))
+            out = torch.empty(T, B, h, w, C, device=dev, dtype=F16)
+            prop = zeros
+            for i, idx in enumerate(order):
+                cur = mid[idx]
+                if i > 0:
+                    n2 = out[order[i - 2]] if i > 1 else zeros
+                    ops.conv2d(S["off0"], [prop, cur, n2], t128, act="leaky", act_param=0.1)
+                    ops.conv2d(S["off2"], [t128], u128, act="leaky", act_param=0.1)
+                    ops.conv2d(S["off4"], [u128], t128, act="leaky", act_param=0.1)
+                    # offset = 5*tanh(first 288), mask = sigmoid(last 144)  (:36-42)
+                    ops.conv2d(S["off6"], [t128], om, act="tanh", out_scale=5.0, act2="sigmoid", act_split=288)
+                    ops.deform_cols(prop, n2, om, cols)
+                    ops.conv2d(S["dcn"], [cols], aligned)
+                    prop = aligned
+                segs = [cur] + ([outs["backward_"][idx]] if name == "forward_" else []) + [prop]
+                ops.conv2d(S["bb0"], segs, t128, act="leaky", act_param=0.1)
+                ops.conv2d(S["bb2"], [t128], out[idx], epi="add", aux1=prop)
+                prop = out[idx]
+            outs[name] = out
+        fused = torch.empty(T * B, h, w, C, device=dev, dtype=F16)
+        ops.conv2d(self.fusion, [outs["backward_"].view(T * B, h, w, C), outs["forward_"].view(T * B, h, w, C)], fused,
+                   epi="add", aux1=mid.view(T * B, h, w, C))
+        return fused
+
+    def _decode(self, prop: torch.Tensor, e1: torch.Tensor) -> torch.Tensor:
+        dev = prop.device
+        n, h, w, _ = prop.shape
+
+        def new(hh, ww, c):
+            return torch.empty(n, hh, ww, c, device=dev, dtype=F16)
+
+        a = ops.conv2d(self.dec2_0, [prop], new(h, w, 128), act="leaky", act_param=0.2)
+        up = ops.upsample2x(a, new(2 * h, 2 * w, 128))
+        b = ops.conv2d(self.dec2_2, [up], new(2 * h, 2 * w, 64), act="leaky", act_param=0.2, epi="add", aux1=e1)
+        c = ops.conv2d(self.dec1_0, [b], new(2 * h, 2 * w, 64), act="leaky", act_param=0.2)
+        up = ops.upsample2x(c, new(4 * h, 4 * w, 64))
+        d = ops.conv2d(self.dec1_2, [up], new(4 * h, 4 * w, 32), act="leaky", act_param=0.2)
+        e = ops.conv2d(self.up_0, [d], new(4 * h, 4 * w, 32), act="leaky", act_param=0.2)
+        up = ops.upsample2x(e, new(8 * h, 8 * w, 32))
+        return ops.conv2d(self.up_2, [up], new(8 * h, 8 * w, 2))
+
+    def __call__(self, flows: torch.Tensor, masks_u8: torch.Tensor, trace: dict | None = None) -> torch.Tensor:
+        """flows fp32 [2,T,H,W,2] (forward, backward), masks u8 [T+1,H,W] (flow masks of the T+1 frames)
+        -> completed + combined flows fp32 [2,T,H,W,2]."""
+        _, T, H, W, _ = flows.shape
+        x = torch.empty(T, 2, H, W, 4, device=flows.device, dtype=F16)
+        ops.rfc_prep(flows, masks_u8, x)
+        e1, mid = self._encode(x)
+        prop = self._propagate(mid)
+        pred = self._decode(prop, e1).view(T, 2, H, W, 2)
+        if trace is not None:
+            trace.update(mid=mid, prop=prop, pred=pred)
+        out = torch.empty_like(flows)
+        ops.flow_combine(pred, flows, masks_u8, out)
+        return out

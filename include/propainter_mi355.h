@@ -198,6 +198,74 @@ typedef struct {
 } pp_convex_upsample_params;
 int32_t pp_convex_upsample(void* stream, const pp_convex_upsample_params* p);
 
+/* ------------------------------------------------------------------------------------
+ * pp_deform_cols -- sampling half of torchvision.ops.deform_conv2d (3x3, stride 1, pad 1,
+ * dilation 1, weight groups 1; call sites recurrent_flow_completion.py:44-53 and
+ * propainter.py:73-82): cols[n][y][x][k*Cin + c] = mask[g*9+k] * bilinear(x[.., c],
+ * (y-1+ky+dy, x-1+kx+dx)) with c in deformable group g = c / (Cin/dg), each out-of-range
+ * corner contributing 0.  The GEMM half is a 1x1 pp_conv2d over 9*Cin channels.
+ * `om` holds the conv_offset output already activated: channels [0, 2*dg*9) offsets
+ * (g*18 + 2k = dy, +1 = dx), channels [2*dg*9, 3*dg*9) modulation masks.
+ * `flow` (optional, fp32 (dx,dy)) is added to every tap offset (propainter.py:67-68).
+ * x may be the concatenation of two channels-last tensors (x0: C0 ch, x1: C1 ch).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype; /* x, om, cols dtype (PP_F16 or PP_F32) */
+  int32_t dg;
+  const void* x0;
+  int64_t x0_C, x0_ldc;
+  const void* x1;
+  int64_t x1_C, x1_ldc;
+  const void* om;
+  int64_t om_ldc;
+  const void* flow; /* fp32 [N][H][W][>=2] or NULL */
+  int64_t flow_ldc;
+  void* cols;
+  int64_t N, H, W;
+} pp_deform_cols_params;
+int32_t pp_deform_cols(void* stream, const pp_deform_cols_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_upsample2x -- F.interpolate(scale_factor=2, mode="bilinear", align_corners=True)
+ * of the `deconv` blocks (recurrent_flow_completion.py:146-159, propainter.py:278-291),
+ * channels-last.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;
+  const void* in;
+  int64_t in_ldc;
+  void* out;
+  int64_t out_ldc;
+  int64_t N, H, W, C;
+} pp_upsample2x_params;
+int32_t pp_upsample2x(void* stream, const pp_upsample2x_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_rfc_prep -- input of RecurrentFlowCompleteNet (recurrent_flow_completion.py:366-377,
+ * 322-325): out[t'][d][y][x] = (flow*(1-m), m, 0) as 4 f16 channels, for direction d = 0
+ * (forward flows, masks[:-1]) and d = 1 (backward flows, masks[1:], TIME-FLIPPED: t' = T-1-t).
+ * flows: fp32 [2][T][H][W][2]; masks: u8 [T+1][H][W]; out: f16 [T][2][H][W][4].
+ * pp_flow_combine -- combine_flow (:389-400) incl. the flip back:
+ * out[d][t] = pred*m + gt*(1-m), pred f16 [T][2][H][W][2] (time-flipped for d = 1).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* flows;
+  const void* masks;
+  void* out;
+  int64_t T, H, W;
+} pp_rfc_prep_params;
+int32_t pp_rfc_prep(void* stream, const pp_rfc_prep_params* p);
+
+typedef struct {
+  const void* pred;
+  int64_t pred_ldc;
+  const void* flows;
+  const void* masks;
+  void* out; /* fp32 [2][T][H][W][2] */
+  int64_t T, H, W;
+} pp_flow_combine_params;
+int32_t pp_flow_combine(void* stream, const pp_flow_combine_params* p);
+
 #ifdef __cplusplus
 }
 #endif

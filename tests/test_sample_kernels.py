@@ -1,0 +1,71 @@
+"""Sampling kernels against their torch formulation (oracle/ops.py restates torchvision's deform_conv2d)."""
+import torch
+import torch.nn.functional as F
+
+from comfyui_propainter_nodes_amd import ops
+from oracle.ops import deform_conv2d
+
+
+def test_deform_conv_matches_contract(backend):
+    """pp_deform_cols + GEMM == deform_conv2d(x=[x0|x1], offset, W, b, mask) for both call-site shapes."""
+    dev = backend
+    g = torch.Generator().manual_seed(11)
+    for c0, c1, with_flow in ((32, 32, False), (32, 0, True)):
+        n, h, w, dg = 2, 9, 11, 16
+        cin = c0 + c1
+        x = torch.randn(n, h, w, cin, generator=g)
+        off = torch.randn(n, h, w, 2 * dg * 9, generator=g) * 2.5  # some samples leave the image
+        msk = torch.rand(n, h, w, dg * 9, generator=g)
+        flow = torch.randn(n, h, w, 2, generator=g) * 2 if with_flow else None
+        wgt = torch.randn(24, cin, 3, 3, generator=g) * 0.1
+        bias = torch.randn(24, generator=g)
+        om = torch.cat([off, msk], -1).to(dev)
+        cols = torch.empty(n, h, w, 9 * cin, device=dev, dtype=torch.float16)
+        xh = x.half().to(dev)
+        ops.deform_cols(xh[..., :c0], xh[..., c0:] if c1 else None, om, cols, dg=dg,
+                        flow=flow.to(dev) if with_flow else None)
+        spec = ops.make_conv_spec(wgt.permute(0, 2, 3, 1).reshape(24, 9 * cin, 1, 1), bias, torch.float16).to(dev)
+        out = torch.empty(n, h, w, 24, device=dev, dtype=torch.float16)
+        ops.conv2d(spec, [cols], out)
+        offr = off.clone()
+        if with_flow:  # propainter.py:67-68: offset + flow.flip(1) tiled -> (dy += flow_y, dx += flow_x)
+            offr = offr + torch.stack([flow[..., 1], flow[..., 0]], -1).repeat(1, 1, 1, dg * 9)
+        ref = deform_conv2d(x.half().float().permute(0, 3, 1, 2), offr.permute(0, 3, 1, 2), wgt.half().float(), bias, 1, 1, 1,
+                            msk.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        err = (out.float().cpu() - ref).abs().max().item()
+        assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
+def test_upsample2x_align_corners(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 7, 9, 16, generator=g)
+    for dt, tol in ((torch.float32, 1e-5), (torch.float16, 2e-3)):
+        out = torch.empty(2, 14, 18, 16, device=dev, dtype=dt)
+        ops.upsample2x(x.to(dt).to(dev), out)
+        ref = F.interpolate(x.to(dt).float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear",
+                            align_corners=True).permute(0, 2, 3, 1)
+        assert (out.float().cpu() - ref).abs().max().item() < tol * ref.abs().max().item()
+
+
+def test_rfc_prep_and_combine(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(13)
+    T, H, W = 3, 6, 8
+    flows = torch.randn(2, T, H, W, 2, generator=g)
+    masks = (torch.rand(T + 1, H, W, generator=g) > 0.5).to(torch.uint8)
+    x = torch.empty(T, 2, H, W, 4, device=dev, dtype=torch.float16)
+    ops.rfc_prep(flows.to(dev), masks.to(dev), x)
+    m = masks.float()
+    ref_f = torch.cat([flows[0] * (1 - m[:-1, ..., None]), m[:-1, ..., None]], -1)
+    ref_b = torch.flip(torch.cat([flows[1] * (1 - m[1:, ..., None]), m[1:, ..., None]], -1), dims=[0])
+    got = x.float().cpu()
+    assert torch.allclose(got[:, 0, ..., :3], ref_f.half().float()) and torch.allclose(got[:, 1, ..., :3], ref_b.half().float())
+    pred = torch.randn(T, 2, H, W, 2, generator=g).half()
+    out = torch.empty(2, T, H, W, 2, device=dev)
+    ops.flow_combine(pred.to(dev), flows.to(dev), masks.to(dev), out)
+    pf = pred[:, 0].float()
+    pb = torch.flip(pred[:, 1].float(), dims=[0])
+    ref0 = pf * m[:-1, ..., None] + flows[0] * (1 - m[:-1, ..., None])
+    ref1 = pb * m[1:, ..., None] + flows[1] * (1 - m[1:, ..., None])
+    assert torch.allclose(out.cpu()[0], ref0) and torch.allclose(out.cpu()[1], ref1)
