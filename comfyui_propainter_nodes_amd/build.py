@@ -74,7 +74,7 @@ def _compile_all(objs_dir: Path, compile_one, link, out: Path, stamp_extra: str,
 
 
 def build_hip(force: bool = False) -> Path:
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=off",
              "-I", str(CSRC), "-I", str(ROOT / "include")]
 
     def compile_one(src: Path, obj: Path) -> None:
@@ -88,7 +88,7 @@ def build_hip(force: bool = False) -> Path:
 
 def build_emu(force: bool = False) -> Path:
     """TEST ONLY: the same kernel sources compiled for x86 against tests/emu/pp_emu.h."""
-    flags = ["-O2", "-std=c++17", "-fPIC", "-DPP_EMU", "-x", "c++", "-Wno-unused-value",
+    flags = ["-O2", "-std=c++17", "-fPIC", "-DPP_EMU", "-x", "c++", "-Wno-unused-value", "-ffp-contract=off",
              "-I", str(CSRC), "-I", str(ROOT / "include"), "-I", str(EMU_DIR)]
 
     def compile_one(src: Path, obj: Path) -> None:

@@ -56,5 +56,10 @@ extern "C" int64_t pp_struct_size(const char* name) {
   PP_SIZEOF_CASE(pp_upsample2x_params)
   PP_SIZEOF_CASE(pp_rfc_prep_params)
   PP_SIZEOF_CASE(pp_flow_combine_params)
+  PP_SIZEOF_CASE(pp_img_prop_step_params)
+  PP_SIZEOF_CASE(pp_pack_encoder_input_params)
+  PP_SIZEOF_CASE(pp_flow_down4_params)
+  PP_SIZEOF_CASE(pp_featprop_aux_params)
+  PP_SIZEOF_CASE(pp_flow_warp_params)
   return -1;
 }

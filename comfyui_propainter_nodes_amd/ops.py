@@ -422,3 +422,80 @@ def flow_combine(pred: torch.Tensor, flows: torch.Tensor, masks_u8: torch.Tensor
     P.flows, P.masks, P.out, P.T, P.H, P.W = flows.data_ptr(), masks_u8.data_ptr(), out.data_ptr(), t, h, w
     _call("pp_flow_combine", out, P)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# flow-guided propagation kernels
+# --------------------------------------------------------------------------------------------
+def img_prop_step(x_cur, m_cur, f_new, m_new, *, f_prev=None, m_prev=None, flow_prop=None, flow_check=None,
+                  mask_input=False) -> None:
+    """One image-propagation step on fp32 [H,W,3] frames / u8 [H,W] masks / fp32 [H,W,2] flows."""
+    check_device(x_cur, m_cur, f_new, m_new, f_prev, m_prev, flow_prop, flow_check)
+    h, w = m_cur.shape
+    P = _lib.STRUCTS["pp_img_prop_step_params"]()
+    first = f_prev is None
+    for name, t in (("x_cur", x_cur), ("m_cur", m_cur), ("f_new", f_new), ("m_new", m_new), ("f_prev", f_prev),
+                    ("m_prev", m_prev), ("flow_prop", flow_prop), ("flow_check", flow_check)):
+        if t is not None:
+            if not t.is_contiguous():
+                raise ValueError(f"img_prop_step: {name} must be dense")
+            setattr(P, name, t.data_ptr())
+    P.H, P.W, P.first, P.mask_input = h, w, int(first), int(mask_input)
+    _call("pp_img_prop_step", f_new, P)
+
+
+def pack_encoder_input(frames, prop, m_in, m_upd, out, updated=None) -> torch.Tensor:
+    """frames/prop fp32 [T,H,W,3], masks u8 [T,H,W] -> out f16 [T,H,W,8] (+ updated fp32 [T,H,W,3])."""
+    check_device(frames, prop, m_in, m_upd, out, updated)
+    for t in (frames, prop, m_in, m_upd, out):
+        if not t.is_contiguous():
+            raise ValueError("pack_encoder_input: tensors must be dense")
+    P = _lib.STRUCTS["pp_pack_encoder_input_params"]()
+    P.frames, P.prop, P.m_in, P.m_upd, P.out = (frames.data_ptr(), prop.data_ptr(), m_in.data_ptr(), m_upd.data_ptr(),
+                                                out.data_ptr())
+    if updated is not None:
+        P.updated = updated.data_ptr()
+    P.total_pixels = m_in.numel()
+    _call("pp_pack_encoder_input", out, P)
+    return out
+
+
+def flow_down4(flows: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """fp32 [N,H,W,2] -> fp32 [N,H/4,W/4,2] (bilinear x1/4, align_corners=False, then /4)."""
+    check_device(flows, out)
+    n, h, w, _ = flows.shape
+    if not flows.is_contiguous() or not out.is_contiguous() or tuple(out.shape) != (n, h // 4, w // 4, 2):
+        raise ValueError("flow_down4: bad shapes")
+    P = _lib.STRUCTS["pp_flow_down4_params"]()
+    setattr(P, "in", flows.data_ptr())
+    P.out, P.N, P.H, P.W = out.data_ptr(), n, h, w
+    _call("pp_flow_down4", out, P)
+    return out
+
+
+def featprop_aux(flow_prop, flow_check, maskpair, out) -> torch.Tensor:
+    """(flow.x, flow.y, fb-valid, m_in, m_updated, 0,0,0) f16 planes for the learnable propagation."""
+    check_device(flow_prop, flow_check, maskpair, out)
+    n, h, w, _ = flow_prop.shape
+    for t in (flow_prop, flow_check, maskpair, out):
+        if not t.is_contiguous():
+            raise ValueError("featprop_aux: tensors must be dense")
+    P = _lib.STRUCTS["pp_featprop_aux_params"]()
+    P.flow_prop, P.flow_check, P.maskpair, P.out = flow_prop.data_ptr(), flow_check.data_ptr(), maskpair.data_ptr(), out.data_ptr()
+    P.N, P.H, P.W = n, h, w
+    _call("pp_featprop_aux", out, P)
+    return out
+
+
+def flow_warp(x: torch.Tensor, flow: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """Bilinear flow warp (zeros padding, align_corners=True) of channels-last features."""
+    check_device(x, flow, out)
+    n, h, w, c, ldc = nhwc_view(x)
+    if not flow.is_contiguous() or flow.dtype != torch.float32 or tuple(flow.shape) != (n, h, w, 2):
+        raise ValueError("flow_warp: bad flow")
+    P = _lib.STRUCTS["pp_flow_warp_params"]()
+    P.dtype, P.x, P.x_ldc, P.flow = dtype_code(x.dtype), x.data_ptr(), ldc, flow.data_ptr()
+    P.out, P.out_ldc = out.data_ptr(), nhwc_view(out)[4]
+    P.N, P.H, P.W, P.C = n, h, w, c
+    _call("pp_flow_warp", out, P)
+    return out

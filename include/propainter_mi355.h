@@ -266,6 +266,91 @@ typedef struct {
 } pp_flow_combine_params;
 int32_t pp_flow_combine(void* stream, const pp_flow_combine_params* p);
 
+/* ------------------------------------------------------------------------------------
+ * pp_img_prop_step -- one step of BidirectionalPropagation(learnable=False)
+ * (propainter.py:149-205 incl. fbConsistencyCheck :27-36 and flow_warp
+ * flow_loss_utils.py:6-51), fused per pixel, fp32 coordinates:
+ *   valid = fbCheck(flow_prop, flow_check);  Fw = warp_nearest(F_prev, flow_prop)
+ *   Mv = bin(warp_bilinear(M_prev, flow_prop));  U = m_cur & valid & !Mv
+ *   F_new = U ? Fw : x_cur;   M_new = m_cur & !(valid & !Mv)
+ * F_*: fp32 [H][W][3] (pitch 3), masks: u8 [H][W], flows: fp32 [H][W][2].
+ * first != 0: F_new = x_cur, M_new = m_cur (the first frame of a pass, :158-160).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* f_prev;
+  const void* m_prev;
+  const void* x_cur;
+  const void* m_cur;
+  const void* flow_prop;
+  const void* flow_check;
+  void* f_new;
+  void* m_new;
+  int64_t H, W;
+  int32_t first;
+  int32_t mask_input; /* != 0: x_cur is used as x_cur*(1-m_cur)  (masked_frames, propainter_inference.py:171) */
+} pp_img_prop_step_params;
+int32_t pp_img_prop_step(void* stream, const pp_img_prop_step_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_pack_encoder_input -- image_propagation's blend (propainter_inference.py:194-198,
+ * 218-221) fused with the generator's input concat (propainter.py:380-388):
+ *   out[t][y][x] = (frames*(1-m) + prop*m (3 ch), m_in, m_updated, 0, 0, 0) as 8 f16
+ * channels; also writes updated_frames fp32 [T][H][W][3] when `updated` != NULL.
+ * frames/prop: fp32 [T][H][W][3]; m_in/m_upd: u8 [T][H][W].
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* frames;
+  const void* prop;
+  const void* m_in;
+  const void* m_upd;
+  void* out;
+  void* updated;
+  int64_t total_pixels;
+} pp_pack_encoder_input_params;
+int32_t pp_pack_encoder_input(void* stream, const pp_pack_encoder_input_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_flow_down4 -- F.interpolate(flow, scale_factor=1/4, bilinear, align_corners=False)/4
+ * (propainter.py:391-408): out[n][i][j] = mean of the 2x2 block at (4i+1..2, 4j+1..2) / 4.
+ * in fp32 [N][H][W][2] -> out fp32 [N][H/4][W/4][2].
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* in;
+  void* out;
+  int64_t N, H, W;
+} pp_flow_down4_params;
+int32_t pp_flow_down4(void* stream, const pp_flow_down4_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_featprop_aux -- per-step conditioning planes of the learnable propagation
+ * (propainter.py:166-188): valid = fbConsistencyCheck(flow_prop, flow_check);
+ * out[n][y][x] = (flow_prop.x, flow_prop.y, valid, mask[..0], mask[..1], 0,0,0) as 8 f16
+ * channels.  flows fp32 [N][h][w][2]; maskpair f16 [N][h][w][8] (channels 0,1 used).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* flow_prop;
+  const void* flow_check;
+  const void* maskpair;
+  void* out;
+  int64_t N, H, W;
+} pp_featprop_aux_params;
+int32_t pp_featprop_aux(void* stream, const pp_featprop_aux_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_flow_warp -- flow_warp(x, flow, "bilinear", zeros, align_corners=True)
+ * (flow_loss_utils.py:6-51) on channels-last features; coordinates in fp32.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;
+  const void* x;
+  int64_t x_ldc;
+  const void* flow; /* fp32 [N][H][W][2] */
+  void* out;
+  int64_t out_ldc;
+  int64_t N, H, W, C;
+} pp_flow_warp_params;
+int32_t pp_flow_warp(void* stream, const pp_flow_warp_params* p);
+
 #ifdef __cplusplus
 }
 #endif
