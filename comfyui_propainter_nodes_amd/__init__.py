@@ -1,0 +1,4 @@
+"""MI355X-native ProPainter inference path behind the ComfyUI ProPainter node API."""
+from .nodes import NODE_CLASS_MAPPINGS, NODE_DISPLAY_NAME_MAPPINGS
+
+__all__ = ["NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"]

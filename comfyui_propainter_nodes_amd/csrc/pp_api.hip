@@ -61,5 +61,11 @@ extern "C" int64_t pp_struct_size(const char* name) {
   PP_SIZEOF_CASE(pp_flow_down4_params)
   PP_SIZEOF_CASE(pp_featprop_aux_params)
   PP_SIZEOF_CASE(pp_flow_warp_params)
+  PP_SIZEOF_CASE(pp_layernorm_params)
+  PP_SIZEOF_CASE(pp_pool_tokens_params)
+  PP_SIZEOF_CASE(pp_window_attention_params)
+  PP_SIZEOF_CASE(pp_fold_params)
+  PP_SIZEOF_CASE(pp_unfold_gelu_params)
+  PP_SIZEOF_CASE(pp_compose_u8_params)
   return -1;
 }

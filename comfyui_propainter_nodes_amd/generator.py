@@ -1,0 +1,304 @@
+"""ProPainter InpaintGenerator on the MI355X (f16 activations, fp32 accumulate / statistics /
+coordinates), replacing InpaintGenerator.forward (model/propainter.py:358-453) and the per-window
+work of feature_propagation (propainter_inference.py:254-281).
+
+Scheduling decisions (all numerically equivalent re-orderings of the reference):
+  * the encoder is per-frame work: it runs ONCE per clip frame (`prepare_clip`), the reference
+    re-encodes every frame for each of the 2-3 windows it appears in;
+  * 1/4-resolution flows, fb-consistency planes and mask planes are per-clip as well;
+  * SoftComp and the decoder only touch the l_t local frames whose output is used (:450-451);
+  * torch.cat -> K segments, residual adds / activations -> conv epilogues, Linear -> 1x1
+    pp_conv2d, F.fold/unfold -> gather kernels on TAP-MAJOR token vectors (weights permuted here).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+F16 = torch.float16
+WIN = (5, 9)
+
+
+def token_grid(h: int, w: int) -> tuple[int, int]:
+    return (h + 6 - 7) // 3 + 1, (w + 6 - 7) // 3 + 1
+
+
+class ClipState:
+    """Per-clip tensors shared by all windows (all on the device)."""
+
+    def __init__(self):
+        self.enc = None        # f16 [T,h,w,128] encoder features
+        self.flow_f = None     # fp32 [T-1,h,w,2] 1/4-res completed forward flows (/4)
+        self.flow_b = None
+        self.aux_b = None      # f16 [T-1,h,w,8] (flow_f, fb-valid, masks of frame t)    -> backward pass at frame t
+        self.aux_f = None      # f16 [T-1,h,w,8] (flow_b, fb-valid, masks of frame t+1)  -> forward pass at frame t+1
+        self.maskpair = None   # f16 [T,h,w,8] (m_in, m_updated, 0...)
+        self.tokmask = None    # CPU bool [T,fh,fw]: MaxPool2d(7,3,3) of the 1/4-res dilated mask
+        self.H = self.W = 0
+
+
+class InpaintGeneratorMI355:
+    def __init__(self, sd: dict, device):
+        self.device = torch.device(device)
+        p = {k: v.float() for k, v in sd.items() if v.is_floating_point()}
+        dev = device
+
+        def conv(name, **kw):
+            return ops.make_conv_spec(p[name + ".weight"], p[name + ".bias"], F16, **kw).to(dev)
+
+        def linear(w, b, **kw):
+            return ops.make_conv_spec(w.reshape(w.shape[0], w.shape[1], 1, 1), b, F16, **kw).to(dev)
+
+        # ---- encoder (propainter.py:234-275) ----------------------------------------------------
+        w0 = p["encoder.layers.0.weight"]  # [64,5,3,3] -> im2col over the 5 packed channels
+        self.enc0_kpad = ops.pad32(45)
+        self.enc0 = ops.make_conv_spec(w0.permute(0, 2, 3, 1).reshape(64, 45, 1, 1), p["encoder.layers.0.bias"], F16,
+                                       seg_channels=[self.enc0_kpad], seg_valid=[45]).to(dev)
+        self.enc2 = conv("encoder.layers.2", padding=1)
+        self.enc4 = conv("encoder.layers.4", stride=2, padding=1)
+        self.enc6 = conv("encoder.layers.6", padding=1)
+        self.enc8 = conv("encoder.layers.8", padding=1)
+        # grouped layers read [x0 group | running group] per group (:269-273)
+        self.enc10 = conv("encoder.layers.10", padding=1, groups=2, seg_channels=[128, 192])
+        self.enc12 = conv("encoder.layers.12", padding=1, groups=4, seg_channels=[64, 128])
+        self.enc14 = conv("encoder.layers.14", padding=1, groups=8, seg_channels=[32, 48])
+        self.enc16 = conv("encoder.layers.16", padding=1, seg_channels=[256, 256])
+        # ---- feature propagation (propainter.py:85-231) -------------------------------------------
+        fp = "feat_prop_module."
+        self.prop = {}
+        for name in ("backward_1", "forward_1"):
+            da = f"{fp}deform_align.{name}."
+            self.prop[name] = {
+                "off0": conv(da + "conv_offset.0", padding=1, seg_channels=[128, 128, 8], seg_valid=[128, 128, 5]),
+                "off2": conv(da + "conv_offset.2", padding=1),
+                "off4": conv(da + "conv_offset.4", padding=1),
+                "off6": conv(da + "conv_offset.6", padding=1),
+                "dcn": ops.make_conv_spec(p[da + "weight"].permute(0, 2, 3, 1).reshape(128, 9 * 128, 1, 1), p[da + "bias"],
+                                          F16).to(dev),
+                "bb0": conv(f"{fp}backbone.{name}.0", padding=1, seg_channels=[128, 128, 8], seg_valid=[128, 128, 2]),
+                "bb2": conv(f"{fp}backbone.{name}.2", padding=1),
+            }
+        self.fuse0 = conv(fp + "fuse.0", padding=1, seg_channels=[128, 128, 8], seg_valid=[128, 128, 2])
+        self.fuse2 = conv(fp + "fuse.2", padding=1)
+        # ---- soft split / composition (sparse_transformer.py:8-64) --------------------------------
+        self.ss = ops.make_conv_spec(p["ss.embedding.weight"].view(512, 128, 7, 7), p["ss.embedding.bias"], F16, stride=3,
+                                     padding=3).to(dev)
+        wsc = p["sc.embedding.weight"].view(128, 49, 512).permute(1, 0, 2).reshape(6272, 512)  # rows -> tap-major
+        bsc = p["sc.embedding.bias"].view(128, 49).t().reshape(6272)
+        self.sc = linear(wsc, bsc)
+        self.sc_bias_conv = conv("sc.bias_conv", padding=1)
+        # ---- transformer blocks ---------------------------------------------------------------------
+        self.blocks = []
+        for i in range(8):
+            t = f"transformers.transformer.{i}."
+            a = t + "attention."
+            wqkv = torch.cat([p[a + "query.weight"], p[a + "key.weight"], p[a + "value.weight"]], 0)
+            bqkv = torch.cat([p[a + "query.bias"], p[a + "key.bias"], p[a + "value.bias"]], 0)
+            wkv = torch.cat([p[a + "key.weight"], p[a + "value.weight"]], 0)
+            bkv = torch.cat([p[a + "key.bias"], p[a + "value.bias"]], 0)
+            w1 = p[t + "mlp.fc1.0.weight"].view(40, 49, 512).permute(1, 0, 2).reshape(1960, 512)
+            b1 = p[t + "mlp.fc1.0.bias"].view(40, 49).t().reshape(1960)
+            w2 = p[t + "mlp.fc2.1.weight"].view(512, 40, 49).permute(0, 2, 1).reshape(512, 1960)
+            self.blocks.append({
+                "qkv": linear(wqkv, bqkv), "kv": linear(wkv, bkv),
+                "proj": linear(p[a + "proj.weight"], p[a + "proj.bias"]),
+                "pool_w": p[a + "pool_layer.weight"].view(512, 16).t().contiguous().to(dev),
+                "pool_b": p[a + "pool_layer.bias"].contiguous().to(dev),
+                "n1w": p[t + "norm1.weight"].to(dev), "n1b": p[t + "norm1.bias"].to(dev),
+                "n2w": p[t + "norm2.weight"].to(dev), "n2b": p[t + "norm2.bias"].to(dev),
+                "fc1": linear(w1, b1), "fc2": linear(w2, p[t + "mlp.fc2.1.bias"]),
+            })
+        # ---- decoder (propainter.py:304-312) ----------------------------------------------------------
+        self.dec0 = conv("decoder.0.conv", padding=1)
+        self.dec2 = conv("decoder.2", padding=1)
+        self.dec4 = conv("decoder.4.conv", padding=1)
+        self.dec6 = conv("decoder.6", padding=1)
+
+    # ------------------------------------------------------------------------------------------------
+    def encode(self, packed: torch.Tensor, chunk: int = 16) -> torch.Tensor:
+        """packed f16 [T,H,W,8] (rgb, m_in, m_updated, 0..) -> f16 [T,H/4,W/4,128]."""
+        dev = packed.device
+        T, H, W, _ = packed.shape
+        h2, w2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        h4, w4 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1
+        out = torch.empty(T, h4, w4, 128, device=dev, dtype=F16)
+        for s in range(0, T, chunk):
+            e = min(T, s + chunk)
+            n = e - s
+
+            def new(hh, ww, c):
+                return torch.empty(n, hh, ww, c, device=dev, dtype=F16)
+
+            cols = ops.im2col(packed[s:e][..., 0:5], new(h2, w2, self.enc0_kpad), 3, 3, stride=2, padding=1)
+            a = ops.conv2d(self.enc0, [cols], new(h2, w2, 64), act="leaky", act_param=0.2)
+            del cols
+            b = ops.conv2d(self.enc2, [a], new(h2, w2, 64), act="leaky", act_param=0.2)
+            c = ops.conv2d(self.enc4, [b], new(h4, w4, 128), act="leaky", act_param=0.2)
+            x0 = ops.conv2d(self.enc6, [c], new(h4, w4, 256), act="leaky", act_param=0.2)
+            d = ops.conv2d(self.enc8, [x0], new(h4, w4, 384), act="leaky", act_param=0.2)
+            f = ops.conv2d(self.enc10, [x0, d], new(h4, w4, 512), act="leaky", act_param=0.2)
+            g = ops.conv2d(self.enc12, [x0, f], new(h4, w4, 384), act="leaky", act_param=0.2)
+            hh = ops.conv2d(self.enc14, [x0, g], new(h4, w4, 256), act="leaky", act_param=0.2)
+            ops.conv2d(self.enc16, [x0, hh], out[s:e], act="leaky", act_param=0.2)
+        return out
+
+    def prepare_clip(self, packed: torch.Tensor, flows: torch.Tensor, masks_in_u8: torch.Tensor,
+                     masks_upd_u8: torch.Tensor, masks_in_cpu: torch.Tensor) -> ClipState:
+        """packed f16 [T,H,W,8]; flows fp32 [2,T-1,H,W,2] (completed); masks u8 [T,H,W] on the device;
+        masks_in_cpu: the same dilated masks on the host (window schedule is host-side integer logic)."""
+        st = ClipState()
+        dev = packed.device
+        T, H, W, _ = packed.shape
+        st.H, st.W = H, W
+        st.enc = self.encode(packed)
+        h, w = st.enc.shape[1:3]
+        ds = torch.empty(2 * (T - 1), h, w, 2, device=dev)
+        ops.flow_down4(flows.view(2 * (T - 1), H, W, 2), ds)
+        st.flow_f, st.flow_b = ds[:T - 1], ds[T - 1:]
+        # nearest x1/4 picks pixel (4i, 4j) (propainter.py:409-417)
+        st.maskpair = torch.zeros(T, h, w, 8, device=dev, dtype=F16)
+        st.maskpair[..., 0] = masks_in_u8[:, ::4, ::4]
+        st.maskpair[..., 1] = masks_upd_u8[:, ::4, ::4]
+        st.aux_b = torch.empty(T - 1, h, w, 8, device=dev, dtype=F16)
+        st.aux_f = torch.empty(T - 1, h, w, 8, device=dev, dtype=F16)
+        ops.featprop_aux(st.flow_f, st.flow_b, st.maskpair[:T - 1], st.aux_b)
+        ops.featprop_aux(st.flow_b, st.flow_f, st.maskpair[1:], st.aux_f)
+        m4 = masks_in_cpu[:, ::4, ::4].float().unsqueeze(1)
+        st.tokmask = F.max_pool2d(m4, 7, 3, 3)[:, 0] > 0
+        return st
+
+    # ------------------------------------------------------------------------------------------------
+    def _feature_propagation(self, st: ClipState, nb: list[int], out_local: torch.Tensor) -> None:
+        """BidirectionalPropagation(learnable=True) over the local frames nb -> out_local [l_t,h,w,128]."""
+        dev = st.enc.device
+        lt = len(nb)
+        g0 = nb[0]
+        x = st.enc[g0:g0 + lt]
+        _, h, w, _ = x.shape
+
+        def buf(c, dt=F16):
+            return torch.empty(1, h, w, c, device=dev, dtype=dt)
+
+        t128, u128, warped, aligned = buf(128), buf(128), buf(128), buf(128)
+        om = buf(432, torch.float32)
+        cols = buf(9 * 128)
+        outs = {}
+        src = x
+        for name in ("backward_1", "forward_1"):
+            S = self.prop[name]
+            out = torch.empty(lt, h, w, 128, device=dev, dtype=F16)
+            order = list(range(lt - 1, -1, -1)) if name == "backward_1" else list(range(lt))
+            prop = None
+            for i, idx in enumerate(order):
+                cur = src[idx:idx + 1]
+                g = g0 + idx
+                mp = st.maskpair[g:g + 1]
+                if i == 0:
+                    prop = cur
+                else:
+                    if name == "backward_1":
+                        flow, aux = st.flow_f[g:g + 1], st.aux_b[g:g + 1]
+                    else:
+                        flow, aux = st.flow_b[g - 1:g], st.aux_f[g - 1:g]
+                    ops.flow_warp(prop, flow, warped)
+                    ops.conv2d(S["off0"], [cur, warped, aux], t128, act="leaky", act_param=0.1)
+                    ops.conv2d(S["off2"], [t128], u128, act="leaky", act_param=0.1)
+                    ops.conv2d(S["off4"], [u128], t128, act="leaky", act_param=0.1)
+                    ops.conv2d(S["off6"], [t128], om, act="tanh", out_scale=3.0, act2="sigmoid", act_split=288)
+                    ops.deform_cols(prop, None, om, cols, flow=flow)
+                    ops.conv2d(S["dcn"], [cols], aligned)
+                    prop = aligned
+                ops.conv2d(S["bb0"], [cur, prop, mp], t128, act="leaky", act_param=0.2)
+                ops.conv2d(S["bb2"], [t128], out[idx:idx + 1], epi="add", aux1=prop)
+                prop = out[idx:idx + 1]
+            outs[name] = out
+            src = out
+        tmp = torch.empty(lt, h, w, 128, device=dev, dtype=F16)
+        ops.conv2d(self.fuse0, [outs["backward_1"], outs["forward_1"], st.maskpair[g0:g0 + lt]], tmp, act="leaky",
+                   act_param=0.2)
+        ops.conv2d(self.fuse2, [tmp], out_local, epi="add", aux1=x)
+
+    def _transformer(self, tok: torch.Tensor, hw: tuple[int, int], win_masked: torch.Tensor) -> torch.Tensor:
+        dev = tok.device
+        t, fh, fw, _ = tok.shape
+        h, w = hw
+        Hp, Wp = math.ceil(fh / WIN[0]) * WIN[0], math.ceil(fw / WIN[1]) * WIN[1]
+        ph, pw = Hp // 4, Wp // 4
+        xn = torch.zeros(t, Hp, Wp, 512, device=dev, dtype=F16)  # pad tokens stay zero (:212-216)
+        qkv = torch.empty(t, Hp, Wp, 1536, device=dev, dtype=F16)
+        pooled = torch.empty(t, ph, pw, 512, device=dev, dtype=F16)
+        pkv = torch.empty(t, ph, pw, 1024, device=dev, dtype=F16)
+        att = torch.empty(t, fh, fw, 512, device=dev, dtype=F16)
+        y = torch.empty(t, fh, fw, 512, device=dev, dtype=F16)
+        f1 = torch.empty(t, fh, fw, 1960, device=dev, dtype=F16)
+        f2 = torch.empty(t, fh, fw, 1960, device=dev, dtype=F16)
+        folded = torch.empty(t, h, w, 40, device=dev, dtype=F16)
+        tok2 = torch.empty_like(tok)
+        t_inds = [torch.arange(i, t, 2, dtype=torch.int32, device=dev) for i in (0, 1)]
+        for i, B in enumerate(self.blocks):
+            ops.layernorm(tok, xn, B["n1w"], B["n1b"])
+            ops.conv2d(B["qkv"], [xn], qkv)
+            ops.pool_tokens(xn, pooled, B["pool_w"], B["pool_b"])
+            ops.conv2d(B["kv"], [pooled], pkv)
+            ops.window_attention(qkv, pkv.view(t, ph * pw, 1024), win_masked, t_inds[i % 2], att)
+            ops.conv2d(B["proj"], [att], tok2, epi="add", aux1=tok)
+            ops.layernorm(tok2, y, B["n2w"], B["n2b"])
+            ops.conv2d(B["fc1"], [y], f1)
+            ops.fold(f1.view(t, fh * fw, 1960), folded, fh, fw, True)
+            ops.unfold_gelu(folded, f2.view(t, fh * fw, 1960), fh, fw)
+            ops.conv2d(B["fc2"], [f2], tok, epi="add", aux1=tok2)
+        return tok
+
+    def window_mask_flags(self, st: ClipState, nb: list[int]) -> torch.Tensor:
+        """Host-side integer logic of sparse_transformer.py:321-326: a 5x9 token window is 'masked'
+        iff any local-frame token mask inside it is set."""
+        tm = st.tokmask[nb[0]:nb[0] + len(nb)].any(0)  # [fh,fw]
+        fh, fw = tm.shape
+        Hp, Wp = math.ceil(fh / WIN[0]) * WIN[0], math.ceil(fw / WIN[1]) * WIN[1]
+        pad = torch.zeros(Hp, Wp, dtype=torch.bool)
+        pad[:fh, :fw] = tm
+        flags = pad.view(Hp // WIN[0], WIN[0], Wp // WIN[1], WIN[1]).permute(0, 2, 1, 3).reshape(-1, WIN[0] * WIN[1]).any(1)
+        return flags.to(torch.int32)
+
+    def forward_window(self, st: ClipState, nb: list[int], refs: list[int], trace: dict | None = None) -> torch.Tensor:
+        """One neighbour+reference window -> tanh image of the local frames, f16 [l_t,H,W,4] (3 used)."""
+        dev = st.enc.device
+        lt, t = len(nb), len(nb) + len(refs)
+        _, h, w, _ = st.enc.shape
+        feat = torch.empty(t, h, w, 128, device=dev, dtype=F16)
+        self._feature_propagation(st, nb, feat[:lt])
+        if refs:
+            feat[lt:] = st.enc[torch.tensor(refs, device=dev)]
+        fh, fw = token_grid(h, w)
+        tok = torch.empty(t, fh, fw, 512, device=dev, dtype=F16)
+        ops.conv2d(self.ss, [feat], tok)
+        flags = self.window_mask_flags(st, nb).to(dev)
+        if trace is not None:
+            trace.update(local_prop=feat[:lt].clone(), tok=tok.clone())
+        tok = self._transformer(tok, (h, w), flags)
+        # soft composition + residual, only for the local frames that are decoded (:443-451)
+        emb = torch.empty(lt, fh, fw, 6272, device=dev, dtype=F16)
+        ops.conv2d(self.sc, [tok[:lt]], emb)
+        comp = torch.empty(lt, h, w, 128, device=dev, dtype=F16)
+        ops.fold(emb.view(lt, fh * fw, 6272), comp, fh, fw, False)
+        enc3 = torch.empty(lt, h, w, 128, device=dev, dtype=F16)
+        ops.conv2d(self.sc_bias_conv, [comp], enc3, epi="add", aux1=feat[:lt])
+        if trace is not None:
+            trace.update(tok_out=tok, enc3=enc3)
+        H, W = st.H, st.W
+
+        def new(hh, ww, c):
+            return torch.empty(lt, hh, ww, c, device=dev, dtype=F16)
+
+        up = ops.upsample2x(enc3, new(2 * h, 2 * w, 128))
+        a = ops.conv2d(self.dec0, [up], new(2 * h, 2 * w, 128), act="leaky", act_param=0.2)
+        b = ops.conv2d(self.dec2, [a], new(2 * h, 2 * w, 64), act="leaky", act_param=0.2)
+        up = ops.upsample2x(b, new(H, W, 64))
+        c = ops.conv2d(self.dec4, [up], new(H, W, 64), act="leaky", act_param=0.2)
+        out = new(H, W, 4)
+        ops.conv2d(self.dec6, [c], out[..., 0:3], act="tanh")
+        return out

@@ -499,3 +499,92 @@ def flow_warp(x: torch.Tensor, flow: torch.Tensor, out: torch.Tensor) -> torch.T
     P.N, P.H, P.W, P.C = n, h, w, c
     _call("pp_flow_warp", out, P)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# transformer kernels
+# --------------------------------------------------------------------------------------------
+def layernorm(x: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """x f16 [T,fh,fw,512] dense -> out f16 [T,Hp,Wp,512] dense (Hp>=fh, Wp>=fw; pad region untouched)."""
+    check_device(x, out, gamma, beta)
+    t, fh, fw, c = x.shape
+    ot, hp, wp, oc = out.shape
+    if not (x.is_contiguous() and out.is_contiguous()) or ot != t or oc != c:
+        raise ValueError("layernorm: bad tensors")
+    P = _lib.STRUCTS["pp_layernorm_params"]()
+    P.x, P.out, P.gamma, P.beta = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    P.T, P.fh, P.fw, P.Hp, P.Wp, P.C, P.eps = t, fh, fw, hp, wp, c, eps
+    _call("pp_layernorm", out, P)
+    return out
+
+
+def pool_tokens(x: torch.Tensor, out: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    check_device(x, out, weight, bias)
+    t, hp, wp, c = x.shape
+    if not (x.is_contiguous() and out.is_contiguous()) or tuple(out.shape) != (t, hp // 4, wp // 4, c):
+        raise ValueError("pool_tokens: bad tensors")
+    P = _lib.STRUCTS["pp_pool_tokens_params"]()
+    P.x, P.out, P.weight, P.bias = x.data_ptr(), out.data_ptr(), weight.data_ptr(), bias.data_ptr()
+    P.T, P.Hp, P.Wp, P.C = t, hp, wp, c
+    _call("pp_pool_tokens", out, P)
+    return out
+
+
+def window_attention(qkv: torch.Tensor, pkv: torch.Tensor, win_masked: torch.Tensor, t_ind: torch.Tensor,
+                     out: torch.Tensor) -> torch.Tensor:
+    """qkv f16 [t,Hp,Wp,1536], pkv f16 [t,npool,1024], win_masked i32 [nwin], t_ind i32 [nt] -> out f16 [t,fh,fw,512]."""
+    check_device(qkv, pkv, win_masked, t_ind, out)
+    t, hp, wp, c3 = qkv.shape
+    _, fh, fw, c = out.shape
+    for tt in (qkv, pkv, out, win_masked, t_ind):
+        if not tt.is_contiguous():
+            raise ValueError("window_attention: tensors must be dense")
+    if c3 != 1536 or c != 512 or pkv.shape[2] != 1024 or win_masked.dtype != torch.int32 or t_ind.dtype != torch.int32:
+        raise ValueError("window_attention: bad tensors")
+    P = _lib.STRUCTS["pp_window_attention_params"]()
+    P.qkv, P.pkv, P.win_masked, P.t_ind, P.out = (qkv.data_ptr(), pkv.data_ptr(), win_masked.data_ptr(), t_ind.data_ptr(),
+                                                  out.data_ptr())
+    P.t, P.nt, P.Hp, P.Wp, P.fh, P.fw, P.npool = t, t_ind.numel(), hp, wp, fh, fw, pkv.shape[1]
+    P.scale = 1.0 / (128 ** 0.5)
+    _call("pp_window_attention", out, P)
+    return out
+
+
+def fold(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int, normalize: bool) -> torch.Tensor:
+    """x f16 [T, fh*fw, 49*C] (tap-major) -> out f16 [T,H,W,C] overlap-add (optionally averaged)."""
+    check_device(x, out)
+    t, h, w, c = out.shape
+    if not (x.is_contiguous() and out.is_contiguous()) or tuple(x.shape) != (t, fh * fw, 49 * c):
+        raise ValueError("fold: bad tensors")
+    P = _lib.STRUCTS["pp_fold_params"]()
+    setattr(P, "in", x.data_ptr())
+    P.out, P.T, P.H, P.W, P.C, P.fh, P.fw, P.normalize = out.data_ptr(), t, h, w, c, fh, fw, int(normalize)
+    _call("pp_fold", out, P)
+    return out
+
+
+def unfold_gelu(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int) -> torch.Tensor:
+    """x f16 [T,H,W,C] -> out f16 [T, fh*fw, 49*C] (tap-major) with exact GELU applied."""
+    check_device(x, out)
+    t, h, w, c = x.shape
+    if not (x.is_contiguous() and out.is_contiguous()) or tuple(out.shape) != (t, fh * fw, 49 * c):
+        raise ValueError("unfold_gelu: bad tensors")
+    P = _lib.STRUCTS["pp_unfold_gelu_params"]()
+    setattr(P, "in", x.data_ptr())
+    P.out, P.T, P.H, P.W, P.C, P.fh, P.fw = out.data_ptr(), t, h, w, c, fh, fw
+    _call("pp_unfold_gelu", out, P)
+    return out
+
+
+def compose_u8(pred: torch.Tensor, frame_ids: torch.Tensor, first: torch.Tensor, masks_u8: torch.Tensor,
+               orig_u8: torch.Tensor, comp_u8: torch.Tensor) -> torch.Tensor:
+    """pred f16 [L,H,W,>=3]; frame_ids/first i32 [L]; masks u8 [T,H,W]; orig/comp u8 [T,H,W,3] (comp updated in place)."""
+    check_device(pred, frame_ids, first, masks_u8, orig_u8, comp_u8)
+    l, h, w, _ = pred.shape
+    P = _lib.STRUCTS["pp_compose_u8_params"]()
+    P.pred, P.pred_ldc = pred.data_ptr(), pred.stride(2)
+    P.frame_ids, P.first, P.masks, P.orig, P.comp = (frame_ids.data_ptr(), first.data_ptr(), masks_u8.data_ptr(),
+                                                     orig_u8.data_ptr(), comp_u8.data_ptr())
+    P.L, P.H, P.W = l, h, w
+    _call("pp_compose_u8", comp_u8, P)
+    return comp_u8

@@ -1,0 +1,170 @@
+"""Inference driver: the MI355X re-design of propainter_inference.py (reference :17-341).
+
+Same temporal policy as the reference (so results are comparable chunk for chunk):
+  compute_flow      :61-99    all adjacent pairs (per-pair results are chunk-invariant)
+  complete_flow     :102-156  sub-videos of `subvideo_length` flows with 5-flow halos
+  image_propagation :159-225  sub-videos of min(100, subvideo_length) frames with 10-frame halos
+  feature_propagation :228-311 sliding neighbour windows + strided reference frames, uint8 compose
+but frames stay resident in HBM for the whole clip: one H2D of uint8 frames + masks, one D2H of
+the composed uint8 frames; no per-window host round trips, no empty_cache() calls.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import imgprop, ops, weights
+from .generator import InpaintGeneratorMI355
+from .raft import RaftFlow
+from .rfc import FlowCompleter
+
+
+@dataclass
+class ProPainterConfig:
+    ref_stride: int
+    neighbor_length: int
+    subvideo_length: int
+    raft_iter: int
+    fp16: str
+    video_length: int
+    device: torch.device
+    process_size: tuple[int, int]
+    use_half: bool = field(init=False)
+
+    def __post_init__(self) -> None:
+        self.use_half = self.fp16 == "enable"
+        if self.device == torch.device("cpu"):
+            self.use_half = False
+
+
+def get_ref_index(mid_neighbor_id: int, neighbor_ids: list[int], config: ProPainterConfig, ref_num: int = -1) -> list[int]:
+    """Reference-frame ids for one window (propainter_inference.py:36-58), incl. its `len > ref_num` quirk."""
+    ref_index: list[int] = []
+    if ref_num == -1:
+        return [i for i in range(0, config.video_length, config.ref_stride) if i not in neighbor_ids]
+    start = max(0, mid_neighbor_id - config.ref_stride * (ref_num // 2))
+    end = min(config.video_length, mid_neighbor_id + config.ref_stride * (ref_num // 2))
+    for i in range(start, end, config.ref_stride):
+        if i not in neighbor_ids:
+            if len(ref_index) > ref_num:
+                break
+            ref_index.append(i)
+    return ref_index
+
+
+def window_schedule(config: ProPainterConfig) -> list[tuple[list[int], list[int]]]:
+    """(neighbor_ids, ref_ids) per window, in the reference's order (:247-262)."""
+    ns = config.neighbor_length // 2
+    ref_num = config.subvideo_length // config.ref_stride if config.video_length > config.subvideo_length else -1
+    out = []
+    for f in range(0, config.video_length, ns):
+        nb = list(range(max(0, f - ns), min(config.video_length, f + ns + 1)))
+        out.append((nb, get_ref_index(f, nb, config, ref_num)))
+    return out
+
+
+@dataclass
+class Models:
+    raft_model: RaftFlow
+    flow_model: FlowCompleter
+    inpaint_model: InpaintGeneratorMI355
+    provenance: str = ""
+
+
+_MODEL_CACHE: dict[str, Models] = {}
+
+
+def initialize_models(device: torch.device, use_half: str = "enable", seed: int = 0) -> Models:
+    """Load + repack the three networks once per process and device (the reference reloads all
+    checkpoints on every node execution, utils/model_utils.py:49-59).  Pretrained checkpoints are
+    read from `weights/` when present, otherwise seeded synthetic weights are used (no network)."""
+    key = str(device)
+    if key not in _MODEL_CACHE:
+        sds, prov = weights.get_state_dicts(seed)
+        _MODEL_CACHE[key] = Models(RaftFlow(sds["raft"], device), FlowCompleter(sds["rfc"], device),
+                                   InpaintGeneratorMI355(sds["gen"], device), prov)
+    return _MODEL_CACHE[key]
+
+
+def models_from_state_dicts(sds: dict, device) -> Models:
+    return Models(RaftFlow(sds["raft"], device), FlowCompleter(sds["rfc"], device), InpaintGeneratorMI355(sds["gen"], device),
+                  "explicit")
+
+
+def compute_flow(raft_model: RaftFlow, frames: torch.Tensor, config: ProPainterConfig) -> torch.Tensor:
+    """frames fp32 [T,H,W,3] -> gt flows fp32 [2,T-1,H,W,2] (forward, backward)."""
+    ff, fb = raft_model(frames, config.raft_iter)
+    return torch.stack([ff, fb], 0)
+
+
+def complete_flow(flow_model: FlowCompleter, flows: torch.Tensor, flow_masks_u8: torch.Tensor, subvideo_length: int) -> torch.Tensor:
+    """flows fp32 [2,T-1,H,W,2], flow masks u8 [T,H,W] -> completed flows fp32 [2,T-1,H,W,2]."""
+    n = flows.shape[1]
+    if n <= subvideo_length:
+        return flow_model(flows, flow_masks_u8)
+    pad = 5
+    out = torch.empty_like(flows)
+    for f in range(0, n, subvideo_length):
+        s, e = max(0, f - pad), min(n, f + subvideo_length + pad)
+        ps, pe = f - s, e - min(n, f + subvideo_length)
+        sub = flow_model(flows[:, s:e].contiguous(), flow_masks_u8[s:e + 1].contiguous())
+        out[:, f:f + (e - s - pe - ps)] = sub[:, ps:e - s - pe]
+    return out
+
+
+def image_propagation(frames: torch.Tensor, masks_u8: torch.Tensor, flows: torch.Tensor, config: ProPainterConfig):
+    """-> (prop_frames fp32 [T,H,W,3], updated_masks u8 [T,H,W]); the blend with the input frames is fused
+    into the encoder-input packing kernel by the caller."""
+    T = frames.shape[0]
+    sub = min(100, config.subvideo_length)
+    if T <= sub:
+        return imgprop.image_propagation(frames, masks_u8, flows)
+    pad = 10
+    prop = torch.empty_like(frames)
+    upd = torch.empty_like(masks_u8)
+    for f in range(0, T, sub):
+        s, e = max(0, f - pad), min(T, f + sub + pad)
+        ps, pe = f - s, e - min(T, f + sub)
+        p, m = imgprop.image_propagation(frames[s:e], masks_u8[s:e], flows[:, s:e - 1].contiguous())
+        n = e - s - pe - ps
+        prop[f:f + n] = p[ps:ps + n]
+        upd[f:f + n] = m[ps:ps + n]
+    return prop, upd
+
+
+def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, config: ProPainterConfig,
+                   trace: dict | None = None) -> torch.Tensor:
+    """uint8 host arrays in ([T,H,W,3], [T,H,W], [T,H,W]) -> composed uint8 frames [T,H,W,3] (CPU tensor).
+
+    = process_inpainting (:314-341) + feature_propagation (:228-311) of the reference."""
+    dev = config.device
+    fr_u8 = torch.as_tensor(frames_u8).to(dev)
+    fm = torch.as_tensor(flow_masks_u8).to(dev).contiguous()
+    md_cpu = torch.as_tensor(masks_dilated_u8).contiguous()
+    md = md_cpu.to(dev)
+    T, H, W, _ = fr_u8.shape
+    frames = fr_u8.float().div(255) * 2 - 1  # to_tensors(): x/255*2-1 (image_utils.py:191)
+    gt = compute_flow(models.raft_model, frames, config)
+    pred = complete_flow(models.flow_model, gt, fm, config.subvideo_length)
+    prop, upd = image_propagation(frames, md, pred, config)
+    packed = torch.empty(T, H, W, 8, device=dev, dtype=torch.float16)
+    updated = torch.empty(T, H, W, 3, device=dev) if trace is not None else None
+    ops.pack_encoder_input(frames, prop, md, upd, packed, updated)
+    gen = models.inpaint_model
+    st = gen.prepare_clip(packed, pred, md, upd, md_cpu)
+    comp = torch.zeros(T, H, W, 3, dtype=torch.uint8, device=dev)
+    seen = [False] * T
+    if trace is not None:
+        trace.update(gt_flows=gt, pred_flows=pred, updated_frames=updated, updated_masks=upd, pred_imgs=[])
+    for nb, refs in window_schedule(config):
+        out = gen.forward_window(st, nb, refs)
+        ids = torch.tensor(nb, dtype=torch.int32, device=dev)
+        first = torch.tensor([0 if seen[i] else 1 for i in nb], dtype=torch.int32, device=dev)
+        ops.compose_u8(out, ids, first, md, fr_u8, comp)
+        for i in nb:
+            seen[i] = True
+        if trace is not None:
+            trace["pred_imgs"].append(out[..., :3].float().cpu())
+    return comp.cpu()

@@ -351,6 +351,98 @@ typedef struct {
 } pp_flow_warp_params;
 int32_t pp_flow_warp(void* stream, const pp_flow_warp_params* p);
 
+/* ------------------------------------------------------------------------------------
+ * pp_layernorm -- nn.LayerNorm(512) of the transformer blocks (sparse_transformer.py:413,
+ * 429; eps 1e-5) on f16 tokens [t][fh][fw][C], fp32 statistics.  The output may live in a
+ * zero-padded token grid [t][Hp][Wp][C] (the window padding of :212-216 happens AFTER the
+ * norm, so padded tokens stay exactly zero: the caller zero-fills `out` once).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;
+  void* out;
+  const void* gamma; /* fp32 [C] */
+  const void* beta;  /* fp32 [C] */
+  int64_t T, fh, fw, Hp, Wp, C;
+  float eps;
+} pp_layernorm_params;
+int32_t pp_layernorm(void* stream, const pp_layernorm_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_pool_tokens -- SparseWindowAttention.pool_layer (sparse_transformer.py:170-180,289):
+ * depth-wise Conv2d(C, C, k4, s4, groups=C) over the padded token grid.
+ * x f16 [T][Hp][Wp][C] -> out f16 [T][Hp/4][Wp/4][C]; weight fp32 [16][C] (tap-major), bias fp32 [C].
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;
+  void* out;
+  const void* weight;
+  const void* bias;
+  int64_t T, Hp, Wp, C;
+} pp_pool_tokens_params;
+int32_t pp_pool_tokens(void* stream, const pp_pool_tokens_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_window_attention -- SparseWindowAttention.forward core (sparse_transformer.py:218-385):
+ * per (window, head), flash-style on MFMA, never materialising the rolled/pooled key copies.
+ *   masked window  : queries = the window's 45 tokens of all t frames; keys/values = for each
+ *                    frame in t_ind: 45 own + 148 rolled-neighbour (circular) + all pooled tokens;
+ *   unmasked window: each frame attends to its own 45 tokens.
+ * qkv f16 [t][Hp][Wp][3*512] (q|k|v of the padded grid), pkv f16 [t][npool][2*512] (k|v of the
+ * pooled tokens), win_masked i32 [nwh*nww], t_ind i32 [nt]; out f16 [t][fh][fw][512] (unpadded).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* qkv;
+  const void* pkv;
+  const void* win_masked;
+  const void* t_ind;
+  void* out;
+  int64_t t, nt, Hp, Wp, fh, fw, npool;
+  float scale;
+} pp_window_attention_params;
+int32_t pp_window_attention(void* stream, const pp_window_attention_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_fold / pp_unfold_gelu -- F.fold / F.unfold with kernel 7, stride 3, padding 3
+ * (SoftComp sparse_transformer.py:56-62, FusionFeedForward :95-121).  Token vectors are laid
+ * out TAP-MAJOR: channel (ky*7+kx)*C + c (the host permutes the producing / consuming Linear
+ * weights accordingly).  pp_fold: out[t][y][x][c] = sum of the overlapping taps, divided by the
+ * overlap count when `normalize` (the constant "fold of ones" map of :88-101).
+ * pp_unfold_gelu: re-extract the patches and apply the exact (erf) GELU of fc2 (:83).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* in; /* f16 [T][fh*fw][49*C] */
+  void* out;      /* f16 [T][H][W][C] */
+  int64_t T, H, W, C, fh, fw;
+  int32_t normalize;
+} pp_fold_params;
+int32_t pp_fold(void* stream, const pp_fold_params* p);
+
+typedef struct {
+  const void* in; /* f16 [T][H][W][C] */
+  void* out;      /* f16 [T][fh*fw][49*C] */
+  int64_t T, H, W, C, fh, fw;
+} pp_unfold_gelu_params;
+int32_t pp_unfold_gelu(void* stream, const pp_unfold_gelu_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_compose_u8 -- the uint8 compose of feature_propagation (propainter_inference.py:283-307):
+ *   p = trunc_u8(((pred+1)/2)*255); img = m ? p : orig;
+ *   first visit: comp = img; later: comp = trunc_u8(0.5*comp + 0.5*img)   (window order)
+ * pred f16 [L][H][W][pred_ldc>=3] (tanh already applied), frame_ids i32 [L] (global frame index
+ * of each local frame), first i32 [L]; masks u8 [T][H][W]; orig / comp u8 [T][H][W][3].
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* pred;
+  int64_t pred_ldc;
+  const void* frame_ids;
+  const void* first;
+  const void* masks;
+  const void* orig;
+  void* comp;
+  int64_t L, H, W;
+} pp_compose_u8_params;
+int32_t pp_compose_u8(void* stream, const pp_compose_u8_params* p);
+
 #ifdef __cplusplus
 }
 #endif
