@@ -1,0 +1,165 @@
+"""bench.py -- BASELINE.json metric: inpainted frames/sec end-to-end, 640x360, neighbor_length 10.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path (RAFT -> flow completion -> image propagation ->
+feature propagation + sparse transformer -> uint8 compose) over one synthetic clip of
+BASELINE.json configs[1]: 80 frames, 640x360, neighbor_length 10, ref_stride 10, subvideo_length 80,
+raft_iter 20 (node default), fp16 "enable" (RAFT fp32 like the reference).  Inputs (uint8 frames +
+masks) are resident in HBM when the timed region starts; the composed uint8 frames stay in HBM.
+Weights: pretrained checkpoints when `weights/` holds them, else seeded random weights of the exact
+architecture (no network here) -- stated in `data`.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank processes its own
+80-frame sub-video (the reference's own sub-video unit) -- weak scaling; the timed
+region is bracketed by barrier + synchronize and the MAX over ranks is reported.
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (the MFMA implicit-GEMM conv),
+measured live with HIP events on the launch stream during one extra instrumented step, and
+`cpu_baseline` (the oracle = CPU port of the reference, bounded sample, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+CFG = dict(T=80, H=360, W=640, neighbor_length=10, ref_stride=10, subvideo_length=80, raft_iter=20,
+           mask_dilates=5, flow_mask_dilates=8)
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def make_inputs(T, H, W, mask_dilates, flow_mask_dilates, seed=1234):
+    from comfyui_propainter_nodes_amd import image_utils, synth
+
+    image, mask = synth.synthetic_clip(T, H, W, seed)
+    frames_u8 = image_utils.image_to_uint8_frames(image)
+    icfg = image_utils.ImageConfig(W, H, mask_dilates, flow_mask_dilates, (W, H), T)
+    return image_utils.prepare_frames_and_masks(frames_u8, mask, icfg)
+
+
+def cpu_baseline(sds, n_frames=4):
+    """Time the oracle (CPU port of the reference algorithm) on a bounded sample of the same workload."""
+    from oracle import pipeline as OP
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    frames_u8, fm, md = make_inputs(n_frames, CFG["H"], CFG["W"], CFG["mask_dilates"], CFG["flow_mask_dilates"])
+    frames = (torch.from_numpy(frames_u8).float().div(255) * 2 - 1).permute(0, 3, 1, 2)[None]
+    fmt = torch.from_numpy(fm).float()[None, :, None]
+    mdt = torch.from_numpy(md).float()[None, :, None]
+    t0 = time.time()
+    OP.run(sds, frames, fmt, mdt, [f for f in frames_u8], raft_iter=CFG["raft_iter"], neighbor_length=CFG["neighbor_length"],
+           ref_stride=CFG["ref_stride"], subvideo_length=CFG["subvideo_length"])
+    dt = time.time() - t0
+    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_frames}-frame 640x360 clip, raft_iter {CFG['raft_iter']}, fp32, oracle/ (CPU restatement of the "
+                      f"reference), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=CFG["T"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from comfyui_propainter_nodes_amd import build, lib, ops, pipeline, weights
+
+    if not lib.HIP_LIB.exists():
+        build.build_hip()
+    lib.load()
+    sds, prov = weights.get_state_dicts(0)
+    models = pipeline.models_from_state_dicts(sds, dev)
+    T = args.frames
+    frames_u8, fm, md = make_inputs(T, CFG["H"], CFG["W"], CFG["mask_dilates"], CFG["flow_mask_dilates"], seed=1234 + rank)
+    cfg = pipeline.ProPainterConfig(CFG["ref_stride"], CFG["neighbor_length"], CFG["subvideo_length"], CFG["raft_iter"],
+                                    "enable", T, dev, (CFG["W"], CFG["H"]))
+    fr_d, fm_d, md_d = torch.from_numpy(frames_u8).to(dev), torch.from_numpy(fm).to(dev), torch.from_numpy(md).to(dev)
+
+    def step():
+        return pipeline.run_inpainting(models, fr_d, fm_d, md_d, cfg, to_host=False)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    fps = world * T * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: one extra instrumented step (HIP events on the launch stream)
+    ops.CONV_PROFILE = ops.ConvProfile()
+    step()
+    torch.cuda.synchronize()
+    prof = ops.CONV_PROFILE.summary()
+    ops.CONV_PROFILE = None
+    dom = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
+    roofline = None
+    if dom:
+        d = prof[dom]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": f"conv_igemm_kernel<{dom}> (pp_conv2d, MFMA implicit GEMM)", "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dom], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dom], 4),
+                    "traffic": None, "launches": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / d["n"], 2),
+                    "flops_per_launch": d["flops"] / d["n"], "share_of_step_ms": round(d["ms"], 1),
+                    "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 1), "launches": v["n"]}
+                              for k, v in prof.items() if k != dom}}
+
+    line = {
+        "metric": "inpainted frames/sec end-to-end, 640x360 neighbor=10", "value": round(fps, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 (RAFT f32), fp32 accumulate",
+        "data": f"synthetic clip (seeded texture + sinusoidal motion, centre box mask); weights: {prov}",
+        "config": {"workload": f"{T}-frame 640x360 clip, neighbor_length 10, ref_stride 10, subvideo_length 80, raft_iter 20, "
+                               f"fp16 enable (BASELINE.json configs[1])", "frames_per_gpu": T, "parallelism": f"subvideo x{world}"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sds)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,7 @@ class ClipState:
         self.aux_b = None      # f16 [T-1,h,w,8] (flow_f, fb-valid, masks of frame t)    -> backward pass at frame t
         self.aux_f = None      # f16 [T-1,h,w,8] (flow_b, fb-valid, masks of frame t+1)  -> forward pass at frame t+1
         self.maskpair = None   # f16 [T,h,w,8] (m_in, m_updated, 0...)
-        self.tokmask = None    # CPU bool [T,fh,fw]: MaxPool2d(7,3,3) of the 1/4-res dilated mask
+        self.tokmask = None    # bool [T,fh,fw]: MaxPool2d(7,3,3) of the 1/4-res dilated mask
         self.H = self.W = 0
 
 
@@ -147,9 +147,8 @@ class InpaintGeneratorMI355:
         return out
 
     def prepare_clip(self, packed: torch.Tensor, flows: torch.Tensor, masks_in_u8: torch.Tensor,
-                     masks_upd_u8: torch.Tensor, masks_in_cpu: torch.Tensor) -> ClipState:
-        """packed f16 [T,H,W,8]; flows fp32 [2,T-1,H,W,2] (completed); masks u8 [T,H,W] on the device;
-        masks_in_cpu: the same dilated masks on the host (window schedule is host-side integer logic)."""
+                     masks_upd_u8: torch.Tensor) -> ClipState:
+        """packed f16 [T,H,W,8]; flows fp32 [2,T-1,H,W,2] (completed); masks u8 [T,H,W] on the device."""
         st = ClipState()
         dev = packed.device
         T, H, W, _ = packed.shape
@@ -167,7 +166,8 @@ class InpaintGeneratorMI355:
         st.aux_f = torch.empty(T - 1, h, w, 8, device=dev, dtype=F16)
         ops.featprop_aux(st.flow_f, st.flow_b, st.maskpair[:T - 1], st.aux_b)
         ops.featprop_aux(st.flow_b, st.flow_f, st.maskpair[1:], st.aux_f)
-        m4 = masks_in_cpu[:, ::4, ::4].float().unsqueeze(1)
+        # token masks: MaxPool2d(7,3,3) of the 1/4-res dilated mask (:419-428) -- binary plumbing, kept on device
+        m4 = masks_in_u8[:, ::4, ::4].float().unsqueeze(1)
         st.tokmask = F.max_pool2d(m4, 7, 3, 3)[:, 0] > 0
         return st
 
@@ -254,15 +254,15 @@ class InpaintGeneratorMI355:
         return tok
 
     def window_mask_flags(self, st: ClipState, nb: list[int]) -> torch.Tensor:
-        """Host-side integer logic of sparse_transformer.py:321-326: a 5x9 token window is 'masked'
-        iff any local-frame token mask inside it is set."""
+        """Integer logic of sparse_transformer.py:321-326: a 5x9 token window is 'masked' iff any
+        local-frame token mask inside it is set (computed on the device, no host sync)."""
         tm = st.tokmask[nb[0]:nb[0] + len(nb)].any(0)  # [fh,fw]
         fh, fw = tm.shape
         Hp, Wp = math.ceil(fh / WIN[0]) * WIN[0], math.ceil(fw / WIN[1]) * WIN[1]
-        pad = torch.zeros(Hp, Wp, dtype=torch.bool)
+        pad = torch.zeros(Hp, Wp, dtype=torch.bool, device=tm.device)
         pad[:fh, :fw] = tm
         flags = pad.view(Hp // WIN[0], WIN[0], Wp // WIN[1], WIN[1]).permute(0, 2, 1, 3).reshape(-1, WIN[0] * WIN[1]).any(1)
-        return flags.to(torch.int32)
+        return flags.to(torch.int32).contiguous()
 
     def forward_window(self, st: ClipState, nb: list[int], refs: list[int], trace: dict | None = None) -> torch.Tensor:
         """One neighbour+reference window -> tanh image of the local frames, f16 [l_t,H,W,4] (3 used)."""
@@ -276,7 +276,7 @@ class InpaintGeneratorMI355:
         fh, fw = token_grid(h, w)
         tok = torch.empty(t, fh, fw, 512, device=dev, dtype=F16)
         ops.conv2d(self.ss, [feat], tok)
-        flags = self.window_mask_flags(st, nb).to(dev)
+        flags = self.window_mask_flags(st, nb)
         if trace is not None:
             trace.update(local_prop=feat[:lt].clone(), tok=tok.clone())
         tok = self._transformer(tok, (h, w), flags)

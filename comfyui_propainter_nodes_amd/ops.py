@@ -34,6 +34,33 @@ EPI = {
 PAD = {"zeros": _lib.CONSTS["PP_PAD_ZEROS"], "replicate": _lib.CONSTS["PP_PAD_REPLICATE"]}
 
 
+class ConvProfile:
+    """Per-launch HIP-event timing of pp_conv2d on the launch stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, key: str, flops: float, fn) -> None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.append((key, flops, e0, e1))
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out: dict = {}
+        for key, flops, e0, e1 in self.records:
+            d = out.setdefault(key, {"ms": 0.0, "flops": 0.0, "n": 0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["n"] += 1
+        return out
+
+
+CONV_PROFILE: ConvProfile | None = None
+
+
 def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return PP_F32
@@ -130,6 +157,7 @@ class ConvSpec:
     dw: int = 1
     groups: int = 1
     pad_mode: str = "zeros"
+    cin_valid: int = 0            # real (unpadded) input channels per group, for FLOP accounting
 
     def to(self, device) -> "ConvSpec":
         self.weight = self.weight.to(device)
@@ -155,7 +183,8 @@ def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, 
     seg_channels = seg_channels or [cin_g]
     packed = pack_conv_weight(w, seg_channels, dtype, seg_valid)
     bias = b.detach().float().contiguous() if b is not None else None
-    return ConvSpec(packed, bias, list(seg_channels), cout // groups, kh, kw, sh, sw, ph, pw, dh, dw, groups, pad_mode)
+    return ConvSpec(packed, bias, list(seg_channels), cout // groups, kh, kw, sh, sw, ph, pw, dh, dw, groups, pad_mode,
+                    sum(seg_valid) if seg_valid else cin_g)
 
 
 def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
@@ -224,7 +253,12 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
         P.aux2 = aux2.data_ptr()
         P.aux2_ldc = nhwc_view(aux2)[4]
         P.aux2_zoff = spec.cout if g > 1 else 0
-    L.call("pp_conv2d", stream_handle(out), P)
+    if CONV_PROFILE is not None and out.is_cuda:
+        flops = 2.0 * n * ho * wo * spec.cout * g * spec.cin_valid * spec.kh * spec.kw
+        CONV_PROFILE.launch("f16" if x0.dtype == torch.float16 else "f32", flops,
+                            lambda: L.call("pp_conv2d", stream_handle(out), P))
+    else:
+        L.call("pp_conv2d", stream_handle(out), P)
     return out
 
 
@@ -260,7 +294,11 @@ def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: 
     P.out_ldc = out.stride(2)
     P.out_zoff = out.stride(0)
     P.out_scale = scale
-    L.call("pp_conv2d", stream_handle(out), P)
+    if CONV_PROFILE is not None and out.is_cuda:
+        CONV_PROFILE.launch("f16" if a.dtype == torch.float16 else "f32", 2.0 * z * m * n * k,
+                            lambda: L.call("pp_conv2d", stream_handle(out), P))
+    else:
+        L.call("pp_conv2d", stream_handle(out), P)
     return out
 
 

@@ -135,15 +135,15 @@ def image_propagation(frames: torch.Tensor, masks_u8: torch.Tensor, flows: torch
 
 
 def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, config: ProPainterConfig,
-                   trace: dict | None = None) -> torch.Tensor:
-    """uint8 host arrays in ([T,H,W,3], [T,H,W], [T,H,W]) -> composed uint8 frames [T,H,W,3] (CPU tensor).
+                   trace: dict | None = None, to_host: bool = True) -> torch.Tensor:
+    """uint8 arrays / tensors in ([T,H,W,3], [T,H,W], [T,H,W]) -> composed uint8 frames [T,H,W,3]
+    (CPU tensor, or left in HBM when `to_host` is False).
 
     = process_inpainting (:314-341) + feature_propagation (:228-311) of the reference."""
     dev = config.device
     fr_u8 = torch.as_tensor(frames_u8).to(dev)
     fm = torch.as_tensor(flow_masks_u8).to(dev).contiguous()
-    md_cpu = torch.as_tensor(masks_dilated_u8).contiguous()
-    md = md_cpu.to(dev)
+    md = torch.as_tensor(masks_dilated_u8).to(dev).contiguous()
     T, H, W, _ = fr_u8.shape
     frames = fr_u8.float().div(255) * 2 - 1  # to_tensors(): x/255*2-1 (image_utils.py:191)
     gt = compute_flow(models.raft_model, frames, config)
@@ -153,7 +153,7 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     updated = torch.empty(T, H, W, 3, device=dev) if trace is not None else None
     ops.pack_encoder_input(frames, prop, md, upd, packed, updated)
     gen = models.inpaint_model
-    st = gen.prepare_clip(packed, pred, md, upd, md_cpu)
+    st = gen.prepare_clip(packed, pred, md, upd)
     comp = torch.zeros(T, H, W, 3, dtype=torch.uint8, device=dev)
     seen = [False] * T
     if trace is not None:
@@ -167,4 +167,4 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
             seen[i] = True
         if trace is not None:
             trace["pred_imgs"].append(out[..., :3].float().cpu())
-    return comp.cpu()
+    return comp.cpu() if to_host else comp
