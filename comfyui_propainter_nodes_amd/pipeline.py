@@ -10,6 +10,8 @@ the composed uint8 frames; no per-window host round trips, no empty_cache() call
 """
 from __future__ import annotations
 
+import os
+import time
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -141,19 +143,33 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
 
     = process_inpainting (:314-341) + feature_propagation (:228-311) of the reference."""
     dev = config.device
+    timing = os.environ.get("PP_TIMING") == "1"
+    marks = []
+
+    def mark(name):
+        if timing:
+            torch.cuda.synchronize()
+            marks.append((name, time.perf_counter()))
+            print(f"[pp] {name} done", flush=True)
+
+    mark("start")
     fr_u8 = torch.as_tensor(frames_u8).to(dev)
     fm = torch.as_tensor(flow_masks_u8).to(dev).contiguous()
     md = torch.as_tensor(masks_dilated_u8).to(dev).contiguous()
     T, H, W, _ = fr_u8.shape
     frames = fr_u8.float().div(255) * 2 - 1  # to_tensors(): x/255*2-1 (image_utils.py:191)
     gt = compute_flow(models.raft_model, frames, config)
+    mark("raft")
     pred = complete_flow(models.flow_model, gt, fm, config.subvideo_length)
+    mark("flow_completion")
     prop, upd = image_propagation(frames, md, pred, config)
+    mark("image_propagation")
     packed = torch.empty(T, H, W, 8, device=dev, dtype=torch.float16)
     updated = torch.empty(T, H, W, 3, device=dev) if trace is not None else None
     ops.pack_encoder_input(frames, prop, md, upd, packed, updated)
     gen = models.inpaint_model
     st = gen.prepare_clip(packed, pred, md, upd)
+    mark("encoder+clip_prep")
     comp = torch.zeros(T, H, W, 3, dtype=torch.uint8, device=dev)
     seen = [False] * T
     if trace is not None:
@@ -167,4 +183,7 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
             seen[i] = True
         if trace is not None:
             trace["pred_imgs"].append(out[..., :3].float().cpu())
+    mark("windows(feature_prop+transformer+decoder+compose)")
+    if timing:
+        print("[pp] stage ms: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f}" for a, b in zip(marks, marks[1:])), flush=True)
     return comp.cpu() if to_host else comp
