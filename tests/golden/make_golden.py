@@ -119,6 +119,67 @@ def run_case(name, T, H, W, *, raft_iter, neighbor_length, ref_stride, subvideo_
     return report
 
 
+def host_cases():
+    """Fixtures for the host-side integer logic, produced by the reference's own functions."""
+    import json
+
+    ref = ref_import.load_reference()
+    import reference.propainter_nodes as RN
+    from reference.propainter_inference import ProPainterConfig, get_ref_index
+    from reference.utils import image_utils as RU
+
+    out = {}
+    g = torch.Generator().manual_seed(99)
+    # masks: blobs, single-mask broadcast, soft values, zero dilation, resize path
+    cases = []
+    m1 = torch.zeros(3, 40, 56); m1[:, 10:20, 12:30] = 1.0; m1[1, 25:30, 40:50] = 0.7
+    cases.append((m1, (56, 40, 5, 8, 3)))
+    m2 = (torch.rand(1, 33, 47, generator=g) > 0.97).float()
+    cases.append((m2, (47, 33, 3, 0, 4)))          # width/height not multiples of 8 -> resize to 40x32
+    m3 = torch.rand(2, 24, 32, generator=g) * (torch.rand(2, 24, 32, generator=g) > 0.9)
+    cases.append((m3, (32, 24, 0, 2, 2)))
+    for i, (m, (w, h, md, fmd, T)) in enumerate(cases):
+        cfg = RU.ImageConfig(w, h, md, fmd, (m.shape[2], m.shape[1]), T)
+        fm, dm = RU.read_masks(m, cfg)
+        out[f"mask_in_{i}"] = m.numpy()
+        out[f"mask_par_{i}"] = np.array([w, h, md, fmd, T])
+        out[f"mask_flow_{i}"] = np.stack([np.array(x) // 255 for x in fm]).astype(np.uint8)
+        out[f"mask_dil_{i}"] = np.stack([np.array(x) // 255 for x in dm]).astype(np.uint8)
+    out["n_mask_cases"] = np.array(len(cases))
+    img = torch.rand(3, 30, 44, 3, generator=g) * 1.1 - 0.05  # values outside [0,1] exercise the clip
+    pil = RU.convert_image_to_frames(img)
+    out["frames_in"] = img.numpy()
+    out["frames_u8"] = np.stack([np.array(f) for f in pil])
+    rcfg = RU.ImageConfig(40, 24, 5, 8, pil[0].size, 3)
+    out["frames_resize_to"] = np.array(rcfg.process_size)
+    out["frames_resized"] = np.stack([np.array(f) for f in RU.resize_images(pil, rcfg)])
+    ocases = [(44, 30, 3, 1.2, 1.0), (44, 30, 3, 1.6, 1.9), (40, 24, 3, 1.0, 1.5)]
+    for i, (w, h, T, ws, hs) in enumerate(ocases):
+        cfg = RU.ImageOutpaintConfig(w, h, 5, 8, pil[0].size, T, ws, hs)
+        fr, fm, dm = RU.extrapolation(pil, cfg)
+        out[f"out_par_{i}"] = np.array([w, h, T])
+        out[f"out_scale_{i}"] = np.array([ws, hs])
+        out[f"out_canvas_{i}"] = np.stack([np.array(f) for f in fr])
+        out[f"out_flow_{i}"] = (np.array(fm[0]) // 255).astype(np.uint8)
+        out[f"out_dil_{i}"] = (np.array(dm[0]) // 255).astype(np.uint8)
+    out["n_out_cases"] = np.array(len(ocases))
+    scheds = {}
+    for T, nl, rs, sv in [(16, 10, 10, 80), (80, 10, 10, 80), (640, 10, 10, 80), (160, 20, 10, 80), (9, 4, 2, 4), (37, 6, 3, 10)]:
+        cfg = ProPainterConfig(rs, nl, sv, 20, "disable", T, torch.device("cpu"), (640, 360))
+        ns = nl // 2
+        ref_num = sv // rs if T > sv else -1
+        rows = []
+        for f in range(0, T, ns):
+            nb = list(range(max(0, f - ns), min(T, f + ns + 1)))
+            rows.append([nb, get_ref_index(f, nb, cfg, ref_num)])
+        scheds[f"{T},{nl},{rs},{sv}"] = rows
+    out["schedules_json"] = np.array(json.dumps(scheds))
+    out["api_json"] = np.array(json.dumps({"inpaint_inputs": RN.ProPainterInpaint.INPUT_TYPES(),
+                                           "outpaint_inputs": RN.ProPainterOutpaint.INPUT_TYPES()}))
+    np.savez_compressed(HERE / "host_cases.npz", **out)
+    print("host_cases written")
+
+
 CASES = {
     # small end-to-end clip, global reference frames (T <= subvideo_length)
     "e2e_small": dict(T=6, H=128, W=144, raft_iter=3, neighbor_length=4, ref_stride=2, subvideo_length=80,
@@ -135,6 +196,8 @@ def main():
     ap.add_argument("--no-save", action="store_true")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    if args.case in ("all", "host"):
+        host_cases()
     for name, kw in CASES.items():
         if args.case in ("all", name):
             run_case(name, save=not args.no_save, **kw)

@@ -1,0 +1,110 @@
+"""Host-side integer logic: bit-exact against fixtures minted from the reference (tests/golden/host_cases.npz)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from comfyui_propainter_nodes_amd import image_utils, nodes, pipeline
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def host_cases():
+    return np.load(GOLD / "host_cases.npz", allow_pickle=False)
+
+
+def test_node_api_is_the_reference_api():
+    assert set(nodes.NODE_CLASS_MAPPINGS) == {"ProPainterInpaint", "ProPainterOutpaint"}
+    assert nodes.NODE_DISPLAY_NAME_MAPPINGS == {"ProPainterInpaint": "ProPainter Inpainting",
+                                                "ProPainterOutpaint": "ProPainter Outpainting"}
+    I, O = nodes.ProPainterInpaint, nodes.ProPainterOutpaint
+    assert I.RETURN_TYPES == ("IMAGE", "MASK", "MASK") and I.RETURN_NAMES == ("IMAGE", "FLOW_MASK", "MASK_DILATE")
+    assert I.FUNCTION == "propainter_inpainting" and I.CATEGORY == "ProPainter"
+    assert O.RETURN_TYPES == ("IMAGE", "MASK", "INT", "INT")
+    assert O.RETURN_NAMES == ("IMAGE", "OUTPAINT_MASK", "output_width", "output_height")
+    assert O.FUNCTION == "propainter_outpainting"
+    req = I.INPUT_TYPES()["required"]
+    assert list(req) == ["image", "mask", "width", "height", "mask_dilates", "flow_mask_dilates", "ref_stride",
+                         "neighbor_length", "subvideo_length", "raft_iter", "fp16"]
+    assert req["width"] == ("INT", {"default": 640, "min": 0, "max": 2560}) and req["raft_iter"][1]["default"] == 20
+    assert req["fp16"] == (["enable", "disable"],)
+    oreq = O.INPUT_TYPES()["required"]
+    assert list(oreq)[:5] == ["image", "width", "height", "width_scale", "height_scale"]
+    assert oreq["width_scale"] == ("FLOAT", {"default": 1.2, "min": 0.0, "max": 10.0, "step": 0.01})
+
+
+def test_node_api_matches_reference_fixture(host_cases):
+    """INPUT_TYPES dumped from the reference classes themselves."""
+    import json
+
+    ref = json.loads(str(host_cases["api_json"]))
+    assert json.loads(json.dumps(nodes.ProPainterInpaint.INPUT_TYPES())) == ref["inpaint_inputs"]
+    assert json.loads(json.dumps(nodes.ProPainterOutpaint.INPUT_TYPES())) == ref["outpaint_inputs"]
+
+
+def test_check_inputs_errors():
+    with pytest.raises(Exception, match="Image length must be greater than 1"):
+        nodes.check_inputs(torch.zeros(1, 8, 8, 3), torch.zeros(1, 8, 8))
+    with pytest.raises(Exception, match="same length"):
+        nodes.check_inputs(torch.zeros(4, 8, 8, 3), torch.zeros(3, 8, 8))
+    with pytest.raises(Exception, match="same dimensions"):
+        nodes.check_inputs(torch.zeros(4, 8, 8, 3), torch.zeros(1, 8, 9))
+    nodes.check_inputs(torch.zeros(4, 8, 8, 3), torch.zeros(1, 8, 8))
+
+
+def test_sizes_round_down_to_multiples_of_8():
+    c = image_utils.ImageConfig(320, 180, 5, 8, (320, 180), 16)
+    assert c.process_size == (320, 176)
+    o = image_utils.ImageOutpaintConfig(640, 360, 5, 8, (640, 360), 80, 1.2, 1.0)
+    assert o.process_size == (640, 360) and o.outpaint_size == (768, 360)
+
+
+def test_read_masks_bit_exact(host_cases):
+    for i in range(int(host_cases["n_mask_cases"])):
+        mask = torch.from_numpy(host_cases[f"mask_in_{i}"])
+        w, h, md, fmd, T = [int(v) for v in host_cases[f"mask_par_{i}"]]
+        cfg = image_utils.ImageConfig(w, h, md, fmd, (mask.shape[2], mask.shape[1]), T)
+        fm, dm = image_utils.read_masks(mask, cfg)
+        assert np.array_equal(fm, host_cases[f"mask_flow_{i}"]), i
+        assert np.array_equal(dm, host_cases[f"mask_dil_{i}"]), i
+
+
+def test_frame_conversion_and_resize_bit_exact(host_cases):
+    img = torch.from_numpy(host_cases["frames_in"])
+    u8 = image_utils.image_to_uint8_frames(img)
+    assert np.array_equal(u8, host_cases["frames_u8"])
+    w, h = [int(v) for v in host_cases["frames_resize_to"]]
+    assert np.array_equal(image_utils.resize_frames(u8, (w, h)), host_cases["frames_resized"])
+
+
+def test_extrapolation_bit_exact(host_cases):
+    img = torch.from_numpy(host_cases["frames_in"])
+    u8 = image_utils.image_to_uint8_frames(img)
+    for i in range(int(host_cases["n_out_cases"])):
+        w, h, T = [int(v) for v in host_cases[f"out_par_{i}"][:3]]
+        ws, hs = [float(v) for v in host_cases[f"out_scale_{i}"]]
+        cfg = image_utils.ImageOutpaintConfig(w, h, 5, 8, (u8.shape[2], u8.shape[1]), T, ws, hs)
+        canvas, fm, dm = image_utils.extrapolation(u8, cfg)
+        assert np.array_equal(canvas, host_cases[f"out_canvas_{i}"])
+        assert np.array_equal(fm[0], host_cases[f"out_flow_{i}"]) and np.array_equal(dm[0], host_cases[f"out_dil_{i}"])
+
+
+def test_window_schedules_match_reference(host_cases):
+    import json
+
+    for key, ref in json.loads(str(host_cases["schedules_json"])).items():
+        T, nl, rs, sv = [int(v) for v in key.split(",")]
+        cfg = pipeline.ProPainterConfig(rs, nl, sv, 20, "enable", T, torch.device("cuda"), (640, 360))
+        got = [[nb, refs] for nb, refs in pipeline.window_schedule(cfg)]
+        assert got == ref, key
+
+
+def test_survey_window_counts():
+    """SURVEY.md section 3 table (computed there with the reference's get_ref_index)."""
+    for (T, nl, rs, sv), (nwin, sum_lt, sum_t) in {(16, 10, 10, 80): (4, 34, 37), (80, 10, 10, 80): (16, 170, 275),
+                                                   (640, 10, 10, 80): (128, 1402, 2266), (160, 20, 10, 80): (16, 325, 391)}.items():
+        cfg = pipeline.ProPainterConfig(rs, nl, sv, 20, "enable", T, torch.device("cuda"), (640, 360))
+        s = pipeline.window_schedule(cfg)
+        assert (len(s), sum(len(a) for a, _ in s), sum(len(a) + len(b) for a, b in s)) == (nwin, sum_lt, sum_t)

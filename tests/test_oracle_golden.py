@@ -1,0 +1,35 @@
+"""The oracle pin: oracle/ must reproduce the fixtures minted from the reference itself
+(tests/golden/make_golden.py ran the reference on CPU fp32 and dumped these tensors)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from comfyui_propainter_nodes_amd import weights
+from oracle import pipeline as OP
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.mark.parametrize("case", ["e2e_small", "e2e_chunked"])
+def test_oracle_reproduces_reference_fixture(case):
+    g = np.load(GOLD / f"{case}.npz")
+    T, H, W, iters, nl, rs, sv, _, _, seed = [int(v) for v in g["params"]]
+    sds = weights.synth_state_dicts(seed)
+    torch.set_num_threads(8)
+    frames_u8 = g["frames_u8"]
+    frames = (torch.from_numpy(frames_u8).float().div(255) * 2 - 1).permute(0, 3, 1, 2)[None]
+    fm = torch.from_numpy(g["flow_masks"]).float()[None, :, None]
+    md = torch.from_numpy(g["masks_dilated"]).float()[None, :, None]
+    comp, tr = OP.run(sds, frames, fm, md, [f for f in frames_u8], raft_iter=iters, neighbor_length=nl, ref_stride=rs,
+                      subvideo_length=sv, return_trace=True)
+    assert torch.allclose(tr["gt_flows"][0][0], torch.from_numpy(g["gt_flow_f"]), atol=1e-5)
+    assert torch.allclose(tr["gt_flows"][1][0], torch.from_numpy(g["gt_flow_b"]), atol=1e-5)
+    assert torch.allclose(tr["pred_flows"][0][0], torch.from_numpy(g["pred_flow_f"]).float(), atol=8e-3)  # f16 fixture
+    assert torch.equal(tr["updated_masks"][0, :, 0], torch.from_numpy(g["updated_masks"]).float())
+    assert torch.allclose(tr["updated_frames"][0], torch.from_numpy(g["updated_frames"]).float(), atol=1e-3)
+    pi = torch.cat(tr["pred_imgs"], 0)
+    assert torch.allclose(pi, torch.from_numpy(g["pred_imgs"]).float(), atol=2e-3)
+    out = np.stack(comp, 0)
+    assert np.abs(out.astype(np.int32) - g["out_image"].astype(np.int32)).max() <= 1

@@ -1,0 +1,129 @@
+"""Transformer-side kernels against the oracle's torch formulation (f16 storage, fp32 math; tol 4e-3 rel)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from comfyui_propainter_nodes_amd import ops, weights
+from oracle import generator as OG
+
+H16 = torch.float16
+
+
+def _close(got, ref, tol=4e-3):
+    err = (got.float().cpu() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+def test_layernorm_into_padded_grid(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(2, 6, 8, 512, generator=g) * 2 + 0.5).half()
+    gam, bet = 1 + 0.1 * torch.randn(512, generator=g), 0.1 * torch.randn(512, generator=g)
+    out = torch.zeros(2, 10, 9, 512, dtype=H16, device=dev)
+    ops.layernorm(x.to(dev), out, gam.to(dev), bet.to(dev))
+    ref = F.layer_norm(x.float(), (512,), gam, bet)
+    _close(out[:, :6, :8], ref)
+    assert torch.all(out[:, 6:].float().cpu() == 0) and torch.all(out[:, :, 8:].float().cpu() == 0)
+
+
+def test_pool_tokens(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(2, 8, 12, 64, generator=g).half()
+    w = torch.randn(64, 1, 4, 4, generator=g) * 0.2
+    b = torch.randn(64, generator=g) * 0.1
+    out = torch.empty(2, 2, 3, 64, dtype=H16, device=dev)
+    ops.pool_tokens(x.to(dev), out, w.view(64, 16).t().contiguous().to(dev), b.to(dev))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, b, stride=4, groups=64).permute(0, 2, 3, 1)
+    _close(out, ref)
+
+
+def test_fold_unfold_roundtrip_against_torch(backend):
+    dev = backend
+    g = torch.Generator().manual_seed(33)
+    T, h, w, C = 2, 13, 17, 16
+    fh, fw = (h + 6 - 7) // 3 + 1, (w + 6 - 7) // 3 + 1
+    tok = torch.randn(T, fh * fw, C * 49, generator=g).half()  # torch order: c*49 + tap
+    tap_major = tok.view(T, fh * fw, C, 49).permute(0, 1, 3, 2).reshape(T, fh * fw, 49 * C).contiguous()
+    kw = dict(output_size=(h, w), kernel_size=7, stride=3, padding=3)
+    for normalize in (True, False):
+        out = torch.empty(T, h, w, C, dtype=H16, device=dev)
+        ops.fold(tap_major.to(dev), out, fh, fw, normalize)
+        ref = F.fold(tok.float().permute(0, 2, 1), **kw)
+        if normalize:
+            ref = ref / F.fold(torch.ones(1, 49, fh * fw), **kw)
+        _close(out, ref.permute(0, 2, 3, 1))
+    x = torch.randn(T, h, w, C, generator=g).half()
+    un = torch.empty(T, fh * fw, 49 * C, dtype=H16, device=dev)
+    ops.unfold_gelu(x.to(dev), un, fh, fw)
+    ref = F.gelu(F.unfold(x.float().permute(0, 3, 1, 2), kernel_size=7, stride=3, padding=3)).permute(0, 2, 1)
+    ref = ref.view(T, fh * fw, C, 49).permute(0, 1, 3, 2).reshape(T, fh * fw, 49 * C)
+    _close(un, ref)
+
+
+@pytest.mark.parametrize("fh,fw", [(11, 12), (5, 18)])
+def test_window_attention_matches_oracle(backend, fh, fw):
+    """Masked + unmasked windows, window padding, circular rolled neighbours and pooled tokens."""
+    dev = backend
+    g = torch.Generator().manual_seed(34)
+    t, lt = 4, 3
+    sd = weights.synth_state_dicts(1)["gen"]
+    pre = "transformers.transformer.0.attention."
+    x = torch.randn(1, t, fh, fw, 512, generator=g).half().float()  # "LayerNorm-ed" tokens
+    mask = torch.zeros(1, lt, fh, fw, 1)
+    mask[0, 1, 1:3, 2:5] = 1  # only the first window (and maybe its neighbour) is masked
+    t_ind = torch.arange(1, t, 2)
+    with torch.no_grad():
+        ref = OG.window_attention(sd, pre, x, mask, t_ind)
+    # product path: padded grid, fused qkv / pooled kv GEMMs, fused attention, proj
+    Hp, Wp = math.ceil(fh / 5) * 5, math.ceil(fw / 9) * 9
+    xn = torch.zeros(t, Hp, Wp, 512, dtype=H16, device=dev)
+    xn[:, :fh, :fw] = x[0].half().to(dev)
+
+    def lin(names):
+        w = torch.cat([sd[pre + n + ".weight"] for n in names], 0)
+        b = torch.cat([sd[pre + n + ".bias"] for n in names], 0)
+        return ops.make_conv_spec(w.reshape(w.shape[0], 512, 1, 1), b, H16).to(dev)
+
+    qkv = torch.empty(t, Hp, Wp, 1536, dtype=H16, device=dev)
+    ops.conv2d(lin(["query", "key", "value"]), [xn], qkv)
+    pooled = torch.empty(t, Hp // 4, Wp // 4, 512, dtype=H16, device=dev)
+    ops.pool_tokens(xn, pooled, sd[pre + "pool_layer.weight"].view(512, 16).t().contiguous().to(dev),
+                    sd[pre + "pool_layer.bias"].to(dev))
+    pkv = torch.empty(t, Hp // 4, Wp // 4, 1024, dtype=H16, device=dev)
+    ops.conv2d(lin(["key", "value"]), [pooled], pkv)
+    pm = F.pad(mask[0, :, :, :, 0], (0, Wp - fw, 0, Hp - fh))
+    flags = (F.max_pool2d(pm, (5, 9), (5, 9)).sum(0) > 0).flatten().to(torch.int32)
+    assert 0 < int(flags.sum()) < flags.numel(), "test must cover both window kinds"
+    att = torch.empty(t, fh, fw, 512, dtype=H16, device=dev)
+    ops.window_attention(qkv, pkv.view(t, -1, 1024), flags.to(dev), t_ind.to(torch.int32).to(dev), att)
+    out = torch.empty(t, fh, fw, 512, dtype=H16, device=dev)
+    ops.conv2d(lin(["proj"]), [att], out)
+    _close(out, ref[0], tol=6e-3)
+
+
+def test_compose_u8_bit_exact(backend):
+    """uint8 compose incl. the order-dependent 0.5/0.5 blend with truncation (propainter_inference.py:283-307)."""
+    from oracle import pipeline as OP
+
+    dev = backend
+    g = torch.Generator().manual_seed(35)
+    T, H, W = 5, 12, 16
+    orig = torch.randint(0, 256, (T, H, W, 3), generator=g, dtype=torch.uint8)
+    masks = (torch.rand(T, H, W, generator=g) > 0.5).to(torch.uint8)
+    comp = torch.zeros(T, H, W, 3, dtype=torch.uint8, device=dev)
+    ref_comp = [None] * T
+    seen = [False] * T
+    for nb in ([0, 1, 2], [1, 2, 3, 4], [2, 3, 4]):
+        pred = (torch.rand(len(nb), H, W, 4, generator=g) * 2 - 1).half()
+        ids = torch.tensor(nb, dtype=torch.int32)
+        first = torch.tensor([0 if seen[i] else 1 for i in nb], dtype=torch.int32)
+        ops.compose_u8(pred.to(dev), ids.to(dev), first.to(dev), masks.to(dev), orig.to(dev), comp)
+        for i in nb:
+            seen[i] = True
+        OP.compose_window(ref_comp, pred[..., :3].float().permute(0, 3, 1, 2), masks.float()[None, :, None],
+                          [o.numpy() for o in orig], nb)
+    assert np.array_equal(comp.cpu().numpy(), np.stack(ref_comp, 0))
