@@ -19,6 +19,9 @@
 #include "pp_device.h"
 #include "pp_host.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace pp {
 
 struct ConvK {
@@ -76,6 +79,80 @@ struct Frag<float> {
   typedef f4 piece;
 };
 
+// compile-time loop: the body receives std::integral_constant<int, I>, so every index derived from it
+// is a constant expression (register arrays indexed with it can never fall back to scratch memory)
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <typename OT>
+struct EpiCtx {
+  const float* bias;
+  OT* out;
+  const OT* aux1;
+  const OT* aux2;
+};
+
+// bias + activation(s) + scale + fused epilogue op + channels-last store of 4 consecutive channels
+template <typename OT>
+__device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, f4 accv, int64_t m, int c) {
+  float v[4] = {accv[0], accv[1], accv[2], accv[3]};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int cc = c + r;
+    float t = v[r];
+    if (e.bias && cc < p.Cout) t += e.bias[cc];
+    if (p.act_split > 0 && cc >= p.act_split) {
+      t = apply_act(t, p.act2, p.act_param);
+    } else {
+      t = apply_act(t, p.act, p.act_param);
+      if (p.out_scale != 0.f) t *= p.out_scale;
+    }
+    v[r] = t;
+  }
+  if (p.epi != PP_EPI_NONE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cc = c + r;
+      if (cc < p.Cout) {
+        const float a1 = to_f32(e.aux1[m * p.aux1_ldc + cc]);
+        if (p.epi == PP_EPI_MUL_AUX1) {
+          v[r] *= a1;
+        } else if (p.epi == PP_EPI_ADD_AUX1) {
+          v[r] += a1;
+        } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
+          const float s = v[r] + a1;
+          v[r] = s > 0.f ? s : 0.f;
+        } else if (p.epi == PP_EPI_GRU) {
+          const float h = to_f32(e.aux2[m * p.aux2_ldc + cc]);
+          v[r] = (1.f - a1) * h + a1 * v[r];
+        }
+      }
+    }
+  }
+  OT* dst = e.out + m * p.out_ldc + c;
+  const bool vec_ok = (c + 3 < p.Cout) && ((p.out_ldc & 3) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(OT) - 1)) == 0);
+  if (vec_ok) {
+    if constexpr (sizeof(OT) == 2) {
+      h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<h4*>(dst) = o;
+    } else {
+      f4 o = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f4*>(dst) = o;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (c + r < p.Cout) dst[r] = from_f32<OT>(v[r]);
+  }
+}
+
 template <typename T, typename OT, int WC, int WP, int TC, int TP>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   constexpr int BK = 32;
@@ -130,23 +207,43 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   piece_t xreg[XPASS];
   piece_t wreg[WPASS];
 
-  auto load_chunk = [&](int q) {
-    const int tap = q / p.chunks_per_tap;
-    int rem = q - tap * p.chunks_per_tap;
-    int seg = 0;
+  // K iterator (wave-uniform): chunk -> (tap ky,kx ; segment ; 32-channel chunk inside the segment).
+  // Advanced incrementally (no integer divisions); segment parameters are picked with constant
+  // indices only, so the kernel-argument arrays stay in SGPRs instead of being copied to scratch.
+  int it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
+  const T* it_base = reinterpret_cast<const T*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
+  int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0];
+  auto select_segment = [&](int seg) {
 #pragma unroll
-    for (int s = 0; s < PP_MAX_SEG - 1; ++s) {
-      if (seg == s && s + 1 < p.nseg && rem >= p.seg_chunks[s]) {
-        rem -= p.seg_chunks[s];
-        seg = s + 1;
+    for (int s = 0; s < PP_MAX_SEG; ++s) {
+      if (seg == s) {
+        it_base = reinterpret_cast<const T*>(p.in_ptr[s]) + (int64_t)z * p.in_zoff[s];
+        it_C = p.in_C[s];
+        it_ldc = p.in_ldc[s];
+        it_chunks = p.seg_chunks[s];
       }
     }
-    const int ky = tap / p.kw;
-    const int kx = tap - ky * p.kw;
-    const int c0 = rem * BK + pc * EPP;
-    const bool cvalid = c0 < p.in_C[seg];
-    const T* sbase = reinterpret_cast<const T*>(p.in_ptr[seg]) + (int64_t)z * p.in_zoff[seg];
-    const int ldc = p.in_ldc[seg];
+  };
+  auto advance = [&]() {
+    if (++it_rem == it_chunks) {
+      it_rem = 0;
+      if (++it_seg == p.nseg) {
+        it_seg = 0;
+        if (++it_kx == p.kw) {
+          it_kx = 0;
+          ++it_ky;
+        }
+      }
+      select_segment(it_seg);
+    }
+  };
+
+  auto load_chunk = [&](int q) {
+    const int ky = it_ky, kx = it_kx;
+    const int c0 = it_rem * BK + pc * EPP;
+    const bool cvalid = c0 < it_C;
+    const T* sbase = it_base;
+    const int ldc = it_ldc;
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
       int y = py0[i] + ky * p.dh;
@@ -180,6 +277,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
       }
       wreg[i] = v;
     }
+    advance();
   };
 
   auto store_chunk = [&](int buf) {
@@ -250,69 +348,22 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------
-  const float* bias = p.bias ? p.bias + (int64_t)z * p.bias_zoff : nullptr;
-  OT* out = reinterpret_cast<OT*>(p.out) + (int64_t)z * p.out_zoff;
-  const OT* aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
-  const OT* aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
-#pragma unroll
-  for (int b = 0; b < TP; ++b) {
+  // (accumulator tiles are passed BY VALUE with compile-time indices: any runtime indexing of
+  //  acc[][] would push the whole accumulator array to scratch memory)
+  EpiCtx<OT> e;
+  e.bias = p.bias ? p.bias + (int64_t)z * p.bias_zoff : nullptr;
+  e.out = reinterpret_cast<OT*>(p.out) + (int64_t)z * p.out_zoff;
+  e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
+  e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
+  static_for<TP>([&](auto bi) {
+    constexpr int b = decltype(bi)::value;
     const int64_t m = p_base + wp * TP * 16 + b * 16 + frow;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int a = 0; a < TC; ++a) {
+    static_for<TC>([&](auto ai) {
+      constexpr int a = decltype(ai)::value;
       const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
-      if (c >= p.Cout) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cc = c + r;
-        float t = acc[a][b][r];
-        if (bias && cc < p.Cout) t += bias[cc];
-        if (p.act_split > 0 && cc >= p.act_split) {
-          t = apply_act(t, p.act2, p.act_param);
-        } else {
-          t = apply_act(t, p.act, p.act_param);
-          if (p.out_scale != 0.f) t *= p.out_scale;
-        }
-        v[r] = t;
-      }
-      if (p.epi != PP_EPI_NONE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int cc = c + r;
-          if (cc >= p.Cout) continue;
-          const float a1 = to_f32(aux1[m * p.aux1_ldc + cc]);
-          if (p.epi == PP_EPI_MUL_AUX1) {
-            v[r] *= a1;
-          } else if (p.epi == PP_EPI_ADD_AUX1) {
-            v[r] += a1;
-          } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
-            const float s = v[r] + a1;
-            v[r] = s > 0.f ? s : 0.f;
-          } else if (p.epi == PP_EPI_GRU) {
-            const float h = to_f32(aux2[m * p.aux2_ldc + cc]);
-            v[r] = (1.f - a1) * h + a1 * v[r];
-          }
-        }
-      }
-      OT* dst = out + m * p.out_ldc + c;
-      const bool vec_ok = (c + 3 < p.Cout) && ((p.out_ldc & 3) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(OT) - 1)) == 0);
-      if (vec_ok) {
-        if constexpr (sizeof(OT) == 2) {
-          h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *reinterpret_cast<h4*>(dst) = o;
-        } else {
-          f4 o = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f4*>(dst) = o;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c + r < p.Cout) dst[r] = from_f32<OT>(v[r]);
-      }
-    }
-  }
+      if (m < p.M && c < p.Cout) store_quad<OT>(p, e, acc[a][b], m, c);
+    });
+  });
 }
 
 template <typename T, typename OT, int WC, int WP, int TC, int TP>
