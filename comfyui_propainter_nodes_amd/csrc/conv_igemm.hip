@@ -153,12 +153,16 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
   }
 }
 
-template <typename T, typename OT, int WC, int WP, int TC, int TP>
+template <typename T, typename OT, int WC, int WP, int TC, int TP, bool M32>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   constexpr int BK = 32;
   constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
   constexpr int PPR = BK / EPP;             // pieces per tile row (4 f16, 8 f32)
-  constexpr int LDK = BK + EPP;             // padded LDS row pitch in elements
+  constexpr int LDK = BK;                   // LDS row pitch in elements (no padding: XOR-swizzled pieces)
+  // 16-byte piece p of tile row r is stored at piece p ^ swz(r): conflict-free for the ds_read_b128
+  // lane groups AND the ds_write_b128 groups of gfx950 (f16: 4 pieces/row, f32: 8 pieces/row)
+  constexpr int SWZ_MASK = PPR - 1;
+  constexpr int SWZ_SHIFT = (sizeof(T) == 2) ? 1 : 0;
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
   constexpr int RPP = 256 / PPR;  // rows filled per pass
@@ -286,12 +290,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
       const int r = row0 + i * RPP;
-      if (r < BP) *reinterpret_cast<piece_t*>(xs + r * LDK + pc * EPP) = xreg[i];
+      if (r < BP) *reinterpret_cast<piece_t*>(xs + r * LDK + (pc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * EPP) = xreg[i];
     }
 #pragma unroll
     for (int i = 0; i < WPASS; ++i) {
       const int r = row0 + i * RPP;
-      if (r < BC) *reinterpret_cast<piece_t*>(ws + r * LDK + pc * EPP) = wreg[i];
+      if (r < BC) *reinterpret_cast<piece_t*>(ws + r * LDK + (pc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * EPP) = wreg[i];
     }
   };
 
@@ -300,9 +304,20 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   for (int a = 0; a < TC; ++a)
 #pragma unroll
     for (int b = 0; b < TP; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+  // M32 (f32 only): 32x32x2 MFMA tiles, (TC/2) x (TP/2) accumulators of 16 registers
+  constexpr int TC2 = (TC + 1) / 2, TP2 = (TP + 1) / 2;
+  f16v acc32[TC2][TP2];
+#pragma unroll
+  for (int a = 0; a < TC2; ++a)
+#pragma unroll
+    for (int b = 0; b < TP2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc32[a][b][r] = 0.f;
+  const int r32 = lane & 31, kh32 = lane >> 5;
 
   const int frow = lane & 15;
   const int fgrp = lane >> 4;
+  const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;  // tile rows are multiples of 16 apart: swizzle depends on frow only
 
   load_chunk(0);
   store_chunk(0);
@@ -317,23 +332,42 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     if constexpr (sizeof(T) == 2) {
       h8 af[TC], bf[TP];
 #pragma unroll
-      for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(ws + a * 16 * LDK + fgrp * 8);
+      for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(ws + a * 16 * LDK + (fgrp ^ fswz) * 8);
 #pragma unroll
-      for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const h8*>(xs + b * 16 * LDK + fgrp * 8);
+      for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const h8*>(xs + b * 16 * LDK + (fgrp ^ fswz) * 8);
 #pragma unroll
       for (int a = 0; a < TC; ++a)
 #pragma unroll
         for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(af[a], bf[b], acc[a][b]);
+    } else if constexpr (M32) {
+      const T* xs32 = Xs + buf * BP * LDK + (wp * TP * 16 + r32) * LDK;
+      const T* ws32 = Ws + buf * BC * LDK + (wc * TC * 16 + r32) * LDK;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {  // 8 k per sub-chunk: lane half kh32 supplies k = 4*kh32 + j at step j
+        f4 af[TC2], bf[TP2];
+#pragma unroll
+        for (int a = 0; a < TC2; ++a)
+          af[a] = *reinterpret_cast<const f4*>(ws32 + a * 32 * LDK + ((sub * 2 + kh32) ^ (r32 & 7)) * 4);
+#pragma unroll
+        for (int b = 0; b < TP2; ++b)
+          bf[b] = *reinterpret_cast<const f4*>(xs32 + b * 32 * LDK + ((sub * 2 + kh32) ^ (r32 & 7)) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int a = 0; a < TC2; ++a)
+#pragma unroll
+            for (int b = 0; b < TP2; ++b) acc32[a][b] = mfma_32x32x2_f32(af[a][j], bf[b][j], acc32[a][b]);
+      }
     } else {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         f4 af[TC], bf[TP];
 #pragma unroll
         for (int a = 0; a < TC; ++a)
-          af[a] = *reinterpret_cast<const f4*>(ws + a * 16 * LDK + sub * 16 + fgrp * 4);
+          af[a] = *reinterpret_cast<const f4*>(ws + a * 16 * LDK + ((sub * 4 + fgrp) ^ fswz) * 4);
 #pragma unroll
         for (int b = 0; b < TP; ++b)
-          bf[b] = *reinterpret_cast<const f4*>(xs + b * 16 * LDK + sub * 16 + fgrp * 4);
+          bf[b] = *reinterpret_cast<const f4*>(xs + b * 16 * LDK + ((sub * 4 + fgrp) ^ fswz) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -355,32 +389,56 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   e.out = reinterpret_cast<OT*>(p.out) + (int64_t)z * p.out_zoff;
   e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
-  static_for<TP>([&](auto bi) {
-    constexpr int b = decltype(bi)::value;
-    const int64_t m = p_base + wp * TP * 16 + b * 16 + frow;
-    static_for<TC>([&](auto ai) {
-      constexpr int a = decltype(ai)::value;
-      const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
-      if (m < p.M && c < p.Cout) store_quad<OT>(p, e, acc[a][b], m, c);
+  if constexpr (M32) {
+    static_for<TP2>([&](auto bi) {
+      constexpr int b = decltype(bi)::value;
+      const int64_t m = p_base + wp * TP * 16 + b * 32 + r32;
+      static_for<TC2>([&](auto ai) {
+        constexpr int a = decltype(ai)::value;
+        static_for<4>([&](auto qi) {
+          constexpr int q = decltype(qi)::value;
+          const int c = c_base + wc * TC * 16 + a * 32 + 8 * q + 4 * kh32;
+          const f4 v = {acc32[a][b][4 * q], acc32[a][b][4 * q + 1], acc32[a][b][4 * q + 2], acc32[a][b][4 * q + 3]};
+          if (m < p.M && c < p.Cout) store_quad<OT>(p, e, v, m, c);
+        });
+      });
     });
-  });
+  } else {
+    static_for<TP>([&](auto bi) {
+      constexpr int b = decltype(bi)::value;
+      const int64_t m = p_base + wp * TP * 16 + b * 16 + frow;
+      static_for<TC>([&](auto ai) {
+        constexpr int a = decltype(ai)::value;
+        const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
+        if (m < p.M && c < p.Cout) store_quad<OT>(p, e, acc[a][b], m, c);
+      });
+    });
+  }
 }
 
 template <typename T, typename OT, int WC, int WP, int TC, int TP>
 static int launch_cfg(void* stream, const ConvK& k, int Z) {
+  // f32: 32x32x2 MFMA tiles whenever the per-wave tile is a multiple of 32x32
+  constexpr bool M32 = (sizeof(T) == 4) && (TC % 2 == 0) && (TP % 2 == 0);
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
-  constexpr int LDK = 32 + 16 / (int)sizeof(T);
+  constexpr int LDK = 32;
   const size_t smem = (size_t)2 * (BC + BP) * LDK * sizeof(T);
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
-  pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP>), smem);
-  PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP>), grid, dim3(256), smem, stream, k);
+  pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32>), smem);
+  PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32>), grid, dim3(256), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }
 
 template <typename T, typename OT>
 static int launch_by_cout(void* stream, const ConvK& k, int Z) {
-  if (k.Cout > 64) return launch_cfg<T, OT, 2, 2, 4, 4>(stream, k, Z);   // 128 x 128
+  if (k.Cout > 64) {
+    // 96-wide tiles when they waste clearly fewer output channels than 128-wide ones (Cout 192, 576, ...)
+    const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
+    const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
+    if (waste96 + 32 <= waste128) return launch_cfg<T, OT, 2, 2, 3, 4>(stream, k, Z);  //  96 x 128
+    return launch_cfg<T, OT, 2, 2, 4, 4>(stream, k, Z);                                // 128 x 128
+  }
   if (k.Cout > 32) return launch_cfg<T, OT, 1, 4, 4, 2>(stream, k, Z);   //  64 x 128
   if (k.Cout > 16) return launch_cfg<T, OT, 1, 4, 2, 2>(stream, k, Z);   //  32 x 128
   return launch_cfg<T, OT, 1, 4, 1, 4>(stream, k, Z);                    //  16 x 256

@@ -26,6 +26,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
@@ -44,6 +45,11 @@ __device__ __forceinline__ f4 mfma_16x16x32_f16(h8 a, h8 b, f4 c) {
 }
 __device__ __forceinline__ f4 mfma_16x16x4_f32(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// 32x32x2 f32: lane l holds A[row = l&31][k = l>>5], B[k = l>>5][col = l&31];
+// C/D: lane l holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31], r = 0..15.
+__device__ __forceinline__ f16v mfma_32x32x2_f32(float a, float b, f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
@@ -90,6 +96,27 @@ inline f4 mfma_16x16x4_f32(float a, float b, f4 c) {
     const int row = 4 * (l >> 4) + r;
     float acc = d[r];
     for (int g = 0; g < 4; ++g) acc = fmaf(s[row + 16 * g].a, s[col + 16 * g].b, acc);
+    d[r] = acc;
+  }
+  pp_emu::wave_sync();
+  return d;
+}
+inline f16v mfma_32x32x2_f32(float a, float b, f16v c) {
+  struct Slot {
+    float a, b;
+    unsigned char pad[56];
+  };
+  Slot* s = reinterpret_cast<Slot*>(pp_emu::wave_scratch());
+  const int l = pp_emu::cur->lane;
+  s[l].a = a;
+  s[l].b = b;
+  pp_emu::wave_sync();
+  const int col = l & 31;
+  f16v d = c;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int g = 0; g < 2; ++g) acc = fmaf(s[row + 32 * g].a, s[col + 32 * g].b, acc);
     d[r] = acc;
   }
   pp_emu::wave_sync();

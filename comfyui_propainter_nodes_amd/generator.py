@@ -172,17 +172,37 @@ class InpaintGeneratorMI355:
         return st
 
     # ------------------------------------------------------------------------------------------------
-    def _feature_propagation(self, st: ClipState, nb: list[int], out_local: torch.Tensor) -> None:
-        """BidirectionalPropagation(learnable=True) over the local frames nb -> out_local [l_t,h,w,128]."""
+    def propagate_windows(self, st: ClipState, windows: list[list[int]]) -> list[torch.Tensor]:
+        """BidirectionalPropagation(learnable=True) (propainter.py:118-231) for the local frames of EVERY
+        window of the clip.  Windows are independent, so all windows with the same number of local
+        frames advance through the recurrence together as one batch: step i of the pass is a batch of
+        `nw` images (one per window) instead of `nw` launches of 1 image.  Returns, per window, the
+        propagated local features f16 [l_t,h,w,128]."""
+        result: list[torch.Tensor | None] = [None] * len(windows)
+        groups: dict[int, list[int]] = {}
+        for wi, nb in enumerate(windows):
+            groups.setdefault(len(nb), []).append(wi)
+        for lt, wis in groups.items():
+            out = self._feature_propagation_batch(st, [windows[wi][0] for wi in wis], lt)
+            for j, wi in enumerate(wis):
+                result[wi] = out[:, j]
+        return result  # type: ignore[return-value]
+
+    def _feature_propagation_batch(self, st: ClipState, g0s: list[int], lt: int) -> torch.Tensor:
+        """nw windows starting at clip frames g0s, each with lt local frames -> f16 [lt, nw, h, w, 128]."""
         dev = st.enc.device
-        lt = len(nb)
-        g0 = nb[0]
-        x = st.enc[g0:g0 + lt]
-        _, h, w, _ = x.shape
+        nw = len(g0s)
+        _, h, w, _ = st.enc.shape
+        g0 = torch.tensor(g0s, device=dev)
+
+        def gather(t: torch.Tensor, idx: int) -> torch.Tensor:
+            return t.index_select(0, g0 + idx)  # [nw, ...] rows of the per-clip tensor (plain copy)
 
         def buf(c, dt=F16):
-            return torch.empty(1, h, w, c, device=dev, dtype=dt)
+            return torch.empty(nw, h, w, c, device=dev, dtype=dt)
 
+        x = torch.stack([gather(st.enc, i) for i in range(lt)], 0)            # [lt,nw,h,w,128]
+        mp = torch.stack([gather(st.maskpair, i) for i in range(lt)], 0)      # [lt,nw,h,w,8]
         t128, u128, warped, aligned = buf(128), buf(128), buf(128), buf(128)
         om = buf(432, torch.float32)
         cols = buf(9 * 128)
@@ -190,20 +210,18 @@ class InpaintGeneratorMI355:
         src = x
         for name in ("backward_1", "forward_1"):
             S = self.prop[name]
-            out = torch.empty(lt, h, w, 128, device=dev, dtype=F16)
+            out = torch.empty(lt, nw, h, w, 128, device=dev, dtype=F16)
             order = list(range(lt - 1, -1, -1)) if name == "backward_1" else list(range(lt))
             prop = None
             for i, idx in enumerate(order):
-                cur = src[idx:idx + 1]
-                g = g0 + idx
-                mp = st.maskpair[g:g + 1]
+                cur = src[idx]
                 if i == 0:
                     prop = cur
                 else:
-                    if name == "backward_1":
-                        flow, aux = st.flow_f[g:g + 1], st.aux_b[g:g + 1]
-                    else:
-                        flow, aux = st.flow_b[g - 1:g], st.aux_f[g - 1:g]
+                    if name == "backward_1":   # frame g uses flows_forward[g] / aux_b[g]
+                        flow, aux = gather(st.flow_f, idx), gather(st.aux_b, idx)
+                    else:                      # frame g uses flows_backward[g-1] / aux_f[g-1]
+                        flow, aux = gather(st.flow_b, idx - 1), gather(st.aux_f, idx - 1)
                     ops.flow_warp(prop, flow, warped)
                     ops.conv2d(S["off0"], [cur, warped, aux], t128, act="leaky", act_param=0.1)
                     ops.conv2d(S["off2"], [t128], u128, act="leaky", act_param=0.1)
@@ -212,15 +230,18 @@ class InpaintGeneratorMI355:
                     ops.deform_cols(prop, None, om, cols, flow=flow)
                     ops.conv2d(S["dcn"], [cols], aligned)
                     prop = aligned
-                ops.conv2d(S["bb0"], [cur, prop, mp], t128, act="leaky", act_param=0.2)
-                ops.conv2d(S["bb2"], [t128], out[idx:idx + 1], epi="add", aux1=prop)
-                prop = out[idx:idx + 1]
+                ops.conv2d(S["bb0"], [cur, prop, mp[idx]], t128, act="leaky", act_param=0.2)
+                ops.conv2d(S["bb2"], [t128], out[idx], epi="add", aux1=prop)
+                prop = out[idx]
             outs[name] = out
             src = out
-        tmp = torch.empty(lt, h, w, 128, device=dev, dtype=F16)
-        ops.conv2d(self.fuse0, [outs["backward_1"], outs["forward_1"], st.maskpair[g0:g0 + lt]], tmp, act="leaky",
-                   act_param=0.2)
-        ops.conv2d(self.fuse2, [tmp], out_local, epi="add", aux1=x)
+        n = lt * nw
+        tmp = torch.empty(n, h, w, 128, device=dev, dtype=F16)
+        res = torch.empty(lt, nw, h, w, 128, device=dev, dtype=F16)
+        ops.conv2d(self.fuse0, [outs["backward_1"].view(n, h, w, 128), outs["forward_1"].view(n, h, w, 128), mp.view(n, h, w, 8)],
+                   tmp, act="leaky", act_param=0.2)
+        ops.conv2d(self.fuse2, [tmp], res.view(n, h, w, 128), epi="add", aux1=x.view(n, h, w, 128))
+        return res
 
     def _transformer(self, tok: torch.Tensor, hw: tuple[int, int], win_masked: torch.Tensor) -> torch.Tensor:
         dev = tok.device
@@ -264,13 +285,17 @@ class InpaintGeneratorMI355:
         flags = pad.view(Hp // WIN[0], WIN[0], Wp // WIN[1], WIN[1]).permute(0, 2, 1, 3).reshape(-1, WIN[0] * WIN[1]).any(1)
         return flags.to(torch.int32).contiguous()
 
-    def forward_window(self, st: ClipState, nb: list[int], refs: list[int], trace: dict | None = None) -> torch.Tensor:
-        """One neighbour+reference window -> tanh image of the local frames, f16 [l_t,H,W,4] (3 used)."""
+    def forward_window(self, st: ClipState, nb: list[int], refs: list[int], trace: dict | None = None,
+                       local_prop: torch.Tensor | None = None) -> torch.Tensor:
+        """One neighbour+reference window -> tanh image of the local frames, f16 [l_t,H,W,4] (3 used).
+        `local_prop` = this window's entry of propagate_windows() (computed here when not given)."""
         dev = st.enc.device
         lt, t = len(nb), len(nb) + len(refs)
         _, h, w, _ = st.enc.shape
         feat = torch.empty(t, h, w, 128, device=dev, dtype=F16)
-        self._feature_propagation(st, nb, feat[:lt])
+        if local_prop is None:
+            local_prop = self.propagate_windows(st, [nb])[0]
+        feat[:lt] = local_prop
         if refs:
             feat[lt:] = st.enc[torch.tensor(refs, device=dev)]
         fh, fw = token_grid(h, w)

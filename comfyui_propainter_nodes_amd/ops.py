@@ -37,8 +37,9 @@ PAD = {"zeros": _lib.CONSTS["PP_PAD_ZEROS"], "replicate": _lib.CONSTS["PP_PAD_RE
 class ConvProfile:
     """Per-launch HIP-event timing of pp_conv2d on the launch stream (bench.py's roofline leg)."""
 
-    def __init__(self):
+    def __init__(self, detailed: bool = False):
         self.records = []
+        self.detailed = detailed
 
     def launch(self, key: str, flops: float, fn) -> None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -255,7 +256,10 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
         P.aux2_zoff = spec.cout if g > 1 else 0
     if CONV_PROFILE is not None and out.is_cuda:
         flops = 2.0 * n * ho * wo * spec.cout * g * spec.cin_valid * spec.kh * spec.kw
-        CONV_PROFILE.launch("f16" if x0.dtype == torch.float16 else "f32", flops,
+        key = "f16" if x0.dtype == torch.float16 else "f32"
+        if CONV_PROFILE.detailed:
+            key += f"|k{spec.kh}x{spec.kw} cin{spec.cin_valid} cout{spec.cout} g{g} M{n * ho * wo}"
+        CONV_PROFILE.launch(key, flops,
                             lambda: L.call("pp_conv2d", stream_handle(out), P))
     else:
         L.call("pp_conv2d", stream_handle(out), P)

@@ -174,8 +174,11 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     seen = [False] * T
     if trace is not None:
         trace.update(gt_flows=gt, pred_flows=pred, updated_frames=updated, updated_masks=upd, pred_imgs=[])
-    for nb, refs in window_schedule(config):
-        out = gen.forward_window(st, nb, refs)
+    schedule = window_schedule(config)
+    props = gen.propagate_windows(st, [nb for nb, _ in schedule])
+    mark("feature_propagation(all windows batched)")
+    for wi, (nb, refs) in enumerate(schedule):
+        out = gen.forward_window(st, nb, refs, local_prop=props[wi])
         ids = torch.tensor(nb, dtype=torch.int32, device=dev)
         first = torch.tensor([0 if seen[i] else 1 for i in nb], dtype=torch.int32, device=dev)
         ops.compose_u8(out, ids, first, md, fr_u8, comp)
@@ -183,7 +186,7 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
             seen[i] = True
         if trace is not None:
             trace["pred_imgs"].append(out[..., :3].float().cpu())
-    mark("windows(feature_prop+transformer+decoder+compose)")
+    mark("windows(transformer+decoder+compose)")
     if timing:
         print("[pp] stage ms: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f}" for a, b in zip(marks, marks[1:])), flush=True)
     return comp.cpu() if to_host else comp
