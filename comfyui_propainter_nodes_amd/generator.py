@@ -146,14 +146,15 @@ class InpaintGeneratorMI355:
             ops.conv2d(self.enc16, [x0, hh], out[s:e], act="leaky", act_param=0.2)
         return out
 
-    def prepare_clip(self, packed: torch.Tensor, flows: torch.Tensor, masks_in_u8: torch.Tensor,
-                     masks_upd_u8: torch.Tensor) -> ClipState:
-        """packed f16 [T,H,W,8]; flows fp32 [2,T-1,H,W,2] (completed); masks u8 [T,H,W] on the device."""
+    def prepare_clip(self, packed: torch.Tensor | None, flows: torch.Tensor, masks_in_u8: torch.Tensor,
+                     masks_upd_u8: torch.Tensor, enc: torch.Tensor | None = None) -> ClipState:
+        """packed f16 [T,H,W,8] (or precomputed encoder features `enc` f16 [T,h,w,128], e.g. gathered from
+        other ranks); flows fp32 [2,T-1,H,W,2] (completed); masks u8 [T,H,W] on the device."""
         st = ClipState()
-        dev = packed.device
-        T, H, W, _ = packed.shape
+        T, H, W = masks_in_u8.shape
+        dev = masks_in_u8.device
         st.H, st.W = H, W
-        st.enc = self.encode(packed)
+        st.enc = self.encode(packed) if enc is None else enc
         h, w = st.enc.shape[1:3]
         ds = torch.empty(2 * (T - 1), h, w, 2, device=dev)
         ops.flow_down4(flows.view(2 * (T - 1), H, W, 2), ds)

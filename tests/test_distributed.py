@@ -1,0 +1,100 @@
+"""Multi-GPU path: the sub-video sharding plan and the seam-exchange orchestration.
+
+CPU: the real driver (comfyui_propainter_nodes_amd/distributed.py) over torch.distributed/gloo with world_size 2 and 3,
+stage functions replaced by a toy backend; the sharded result must equal the single-rank result exactly.
+GPU: the same driver with the real MI355X backend and 3 in-process virtual ranks must reproduce the
+single-GPU pipeline bit for bit on the chunked fixture."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from comfyui_propainter_nodes_amd import distributed as D
+from comfyui_propainter_nodes_amd import pipeline
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def test_shard_plan_is_the_reference_chunking():
+    # cfg 4: 640 frames, 8 ranks -> the reference's own 8 sub-videos (propainter_inference.py:115-144,172-212)
+    for r in range(8):
+        p = D.ShardPlan(640, 80, 8, r)
+        assert p.frames == (80 * r, 80 * r + 80)
+        assert p.flow_chunks() == [(80 * r, min(639, 80 * r + 80), max(0, 80 * r - 5), min(639, 80 * r + 85))]
+        assert p.frame_chunks() == [(80 * r, 80 * r + 80, max(0, 80 * r - 10), min(640, 80 * r + 90))]
+    # uneven: 9 frames, sub-videos of 4, 2 ranks -> chunks {0,1} and {2}
+    p0, p1 = D.ShardPlan(9, 4, 2, 0), D.ShardPlan(9, 4, 2, 1)
+    assert p0.frames == (0, 8) and p1.frames == (8, 9)
+    assert p0.flow_chunks() == [(0, 4, 0, 8), (4, 8, 0, 8)] and p1.flow_chunks() == []
+    assert p1.frame_chunks() == [(8, 9, 0, 9)] and p1.raft_frames() == (0, 0)
+    covered = sorted(i for r in range(3) for i in range(*D.ShardPlan(37, 10, 3, r).frames))
+    assert covered == list(range(37))
+
+
+def _toy_inputs(T, H=6, W=8):
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (T, H, W, 3), generator=g, dtype=torch.uint8)
+    md = (torch.rand(T, H, W, generator=g) > 0.5).to(torch.uint8)
+    fm = (torch.rand(T, H, W, generator=g) > 0.4).to(torch.uint8)
+    return frames, fm, md
+
+
+def _cfg(T, nl, rs, sv):
+    return pipeline.ProPainterConfig(rs, nl, sv, 2, "enable", T, torch.device("cpu"), (8, 6))
+
+
+def _worker(rank, world, port, T, nl, rs, sv, out_dir):
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).parent))
+    from toy_backend import ToyBackend
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames, fm, md = _toy_inputs(T)
+    res = D.run_distributed(ToyBackend(), _cfg(T, nl, rs, sv), frames, fm, md)
+    torch.save(res, Path(out_dir) / f"r{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T,nl,rs,sv", [(2, 40, 6, 3, 10), (3, 37, 4, 2, 10), (2, 9, 4, 2, 4)])
+def test_sharded_equals_single_rank_over_gloo(tmp_path, world, T, nl, rs, sv):
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).parent))
+    from toy_backend import ToyBackend
+
+    frames, fm, md = _toy_inputs(T)
+    ref = D.run_simulated(lambda r: ToyBackend(), 1, _cfg(T, nl, rs, sv), frames, fm, md)[0]
+    port = 29500 + (os.getpid() + world * 7 + T) % 2000
+    mp.spawn(_worker, args=(world, port, T, nl, rs, sv, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(tmp_path / f"r{r}.pt")
+        assert got.shape == ref.shape and torch.equal(got, ref), f"rank {r} differs from the single-rank result"
+    # the in-process simulator (used for the single-GPU functional test) follows the same code path
+    sim = D.run_simulated(lambda r: ToyBackend(), world, _cfg(T, nl, rs, sv), frames, fm, md)
+    assert all(torch.equal(s, ref) for s in sim)
+    assert ref.float().std() > 10  # the toy clip is not degenerate
+
+
+@pytest.mark.gpu
+def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib):
+    from comfyui_propainter_nodes_amd import weights
+
+    g = np.load(GOLD / "e2e_chunked.npz")
+    T, H, W, iters, nl, rs, sv, _, _, seed = [int(v) for v in g["params"]]
+    dev = torch.device("cuda:0")
+    models = pipeline.models_from_state_dicts(weights.synth_state_dicts(seed), dev)
+    cfg = pipeline.ProPainterConfig(rs, nl, sv, iters, "enable", T, dev, (W, H))
+    fr, fm, md = (torch.from_numpy(g[k]).to(dev) for k in ("frames_u8", "flow_masks", "masks_dilated"))
+    single = pipeline.run_inpainting(models, fr, fm, md, cfg)
+    for world in (2, 3):
+        res = D.run_simulated(lambda r: D.GpuBackend(models, cfg), world, cfg, fr, fm, md)
+        for r in range(world):
+            assert torch.equal(res[r].cpu(), single), f"world {world} rank {r}"
