@@ -10,9 +10,10 @@ masks) are resident in HBM when the timed region starts; the composed uint8 fram
 Weights: pretrained checkpoints when `weights/` holds them, else seeded random weights of the exact
 architecture (no network here) -- stated in `data`.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank processes its own
-80-frame sub-video (the reference's own sub-video unit) -- weak scaling; the timed
-region is bracketed by barrier + synchronize and the MAX over ranks is reported.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): ONE clip of 80*N frames is sharded
+into the reference's own 80-frame sub-videos, one per rank (BASELINE.json configs[3] at N = 8), with the
+seam exchanges of comfyui_propainter_nodes_amd/distributed.py (all_gather over xGMI) inside the timed region -- weak scaling
+(frames per GPU fixed); barrier + synchronize on both sides, MAX over ranks.
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (the MFMA implicit-GEMM conv),
 measured live with HIP events on the launch stream during one extra instrumented step, and
@@ -81,14 +82,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # (PP_DIST_BACKEND=gloo lets 2 ranks share one GPU for functional tests)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist_backend = os.environ.get("PP_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     from comfyui_propainter_nodes_amd import build, lib, ops, pipeline, weights
 
@@ -97,14 +103,22 @@ def main():
     lib.load()
     sds, prov = weights.get_state_dicts(0)
     models = pipeline.models_from_state_dicts(sds, dev)
-    T = args.frames
-    frames_u8, fm, md = make_inputs(T, CFG["H"], CFG["W"], CFG["mask_dilates"], CFG["flow_mask_dilates"], seed=1234 + rank)
+    T = args.frames * world
+    frames_u8, fm, md = make_inputs(T, CFG["H"], CFG["W"], CFG["mask_dilates"], CFG["flow_mask_dilates"], seed=1234)
     cfg = pipeline.ProPainterConfig(CFG["ref_stride"], CFG["neighbor_length"], CFG["subvideo_length"], CFG["raft_iter"],
                                     "enable", T, dev, (CFG["W"], CFG["H"]))
     fr_d, fm_d, md_d = torch.from_numpy(frames_u8).to(dev), torch.from_numpy(fm).to(dev), torch.from_numpy(md).to(dev)
 
-    def step():
-        return pipeline.run_inpainting(models, fr_d, fm_d, md_d, cfg, to_host=False)
+    if world > 1:
+        from comfyui_propainter_nodes_amd import distributed as D
+
+        backend = D.GpuBackend(models, cfg)
+
+        def step():
+            return D.run_distributed(backend, cfg, fr_d, fm_d, md_d)
+    else:
+        def step():
+            return pipeline.run_inpainting(models, fr_d, fm_d, md_d, cfg, to_host=False)
 
     for _ in range(args.warmup):
         step()
@@ -122,11 +136,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
-    fps = world * T * args.steps / elapsed
+    fps = T * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: one extra instrumented step (HIP events on the launch stream)
     ops.CONV_PROFILE = ops.ConvProfile()
@@ -152,7 +166,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 (RAFT f32), fp32 accumulate",
         "data": f"synthetic clip (seeded texture + sinusoidal motion, centre box mask); weights: {prov}",
         "config": {"workload": f"{T}-frame 640x360 clip, neighbor_length 10, ref_stride 10, subvideo_length 80, raft_iter 20, "
-                               f"fp16 enable (BASELINE.json configs[1])", "frames_per_gpu": T, "parallelism": f"subvideo x{world}"},
+                               f"fp16 enable (BASELINE.json configs[{1 if world == 1 else 3}])", "frames_per_gpu": T // world,
+                   "parallelism": f"subvideo x{world}" + (" (one clip, seam all_gather over RCCL)" if world > 1 else "")},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -245,11 +245,18 @@ def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8,
 
     plan = ShardPlan(config.video_length, config.subvideo_length, dist.get_world_size(group), dist.get_rank(group))
     gen = run_rank(backend, plan, config, frames_u8, flow_masks_u8, masks_dilated_u8)
+    via_host = dist.get_backend(group) == "gloo"  # gloo has no device all_gather: stage through the host (tests only)
     try:
         t = next(gen)
         while True:
-            out = [torch.empty_like(t) for _ in range(plan.world)]
-            dist.all_gather(out, t.contiguous(), group=group)
+            if via_host and t.is_cuda:
+                th = t.cpu()
+                outh = [torch.empty_like(th) for _ in range(plan.world)]
+                dist.all_gather(outh, th, group=group)
+                out = [o.to(t.device) for o in outh]
+            else:
+                out = [torch.empty_like(t) for _ in range(plan.world)]
+                dist.all_gather(out, t.contiguous(), group=group)
             t = gen.send(out)
     except StopIteration as stop:
         return stop.value
