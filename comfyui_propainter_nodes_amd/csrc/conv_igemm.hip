@@ -19,6 +19,8 @@
 #include "pp_device.h"
 #include "pp_host.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 #include <utility>
 
@@ -432,16 +434,28 @@ static int launch_cfg(void* stream, const ConvK& k, int Z) {
 
 template <typename T, typename OT>
 static int launch_by_cout(void* stream, const ConvK& k, int Z) {
+  // Small problems (the per-step convolutions of the two recurrences: M = 2*45*80 or 90*160 pixels) would
+  // fill only a fraction of the 256 CUs with 128-pixel tiles: switch to 32-pixel tiles (4x the work-groups).
+  const int64_t blocks128 = ((k.M + 127) / 128) * ((k.Cout + 127) / 128) * Z;
+  static const int forced = [] {  // PP_CONV_TILE=large|small pins the choice (tests cover both tile families)
+    const char* e = getenv("PP_CONV_TILE");
+    return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0));
+  }();
+  const bool small = forced == 2 || (forced == 0 && blocks128 < 224);
   if (k.Cout > 64) {
+    if (small) return launch_cfg<T, OT, 4, 1, 2, 2>(stream, k, Z);                     // 128 x  32
     // 96-wide tiles when they waste clearly fewer output channels than 128-wide ones (Cout 192, 576, ...)
     const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
     const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
     if (waste96 + 32 <= waste128) return launch_cfg<T, OT, 2, 2, 3, 4>(stream, k, Z);  //  96 x 128
     return launch_cfg<T, OT, 2, 2, 4, 4>(stream, k, Z);                                // 128 x 128
   }
-  if (k.Cout > 32) return launch_cfg<T, OT, 1, 4, 4, 2>(stream, k, Z);   //  64 x 128
-  if (k.Cout > 16) return launch_cfg<T, OT, 1, 4, 2, 2>(stream, k, Z);   //  32 x 128
-  return launch_cfg<T, OT, 1, 4, 1, 4>(stream, k, Z);                    //  16 x 256
+  if (k.Cout > 32) {
+    if (small) return launch_cfg<T, OT, 2, 2, 2, 1>(stream, k, Z);                     //  64 x  32
+    return launch_cfg<T, OT, 1, 4, 4, 2>(stream, k, Z);                                //  64 x 128
+  }
+  if (k.Cout > 16) return launch_cfg<T, OT, 1, 4, 2, 2>(stream, k, Z);                 //  32 x 128
+  return launch_cfg<T, OT, 1, 4, 1, 4>(stream, k, Z);                                  //  16 x 256
 }
 
 }  // namespace pp

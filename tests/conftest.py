@@ -49,7 +49,7 @@ def hip_lib():
 
 
 @pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
-def backend(request):
+def backend(request, monkeypatch):
     """Run a kernel test on the emulator (CPU suite) and on the MI355X (gpu suite)."""
     import torch
 

@@ -30,8 +30,27 @@ def _ref_input(x, segC, groups):
     return torch.cat(parts, 3).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
-def test_conv2d_matches_torch(backend, case):
+@pytest.mark.parametrize("be", ["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("tile", ["large", "small"])
+def test_conv2d_matches_torch(be, tile):
+    """Every case on both tile families (128-pixel tiles / 32-pixel tiles for small problems).  The tile
+    choice is read once per process (PP_CONV_TILE), so each family runs in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import torch as _t
+
+    if be == "hip" and not _t.cuda.is_available():
+        pytest.skip("no GPU visible")
+    root = str(Path(__file__).resolve().parent.parent)
+    env = dict(os.environ, PP_CONV_TILE=tile, PP_TEST_BACKEND=be, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def _run_case(backend, case):
     dt, N, H, W, segC, Cout, k, s, p, d, groups, act = case
     dev = backend
     g = torch.Generator().manual_seed(1234)
@@ -95,3 +114,23 @@ def test_conv2d_replicate_pad_and_batched_gemm(backend):
     ops.batched_gemm_nt(f1.to(dev), f2.to(dev), vol, scale=1.0 / 16)
     ref = torch.einsum("bpc,bqc->bpq", f1[:, 0], f2) / 16
     assert torch.allclose(vol.cpu()[:, 0], ref, atol=1e-5)
+
+
+if __name__ == "__main__":  # child process of test_conv2d_matches_torch
+    import os
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from comfyui_propainter_nodes_amd import build, lib
+
+    if os.environ["PP_TEST_BACKEND"] == "emu":
+        build.build_emu()
+        lib.load_emulator()
+        dev = torch.device("cpu")
+    else:
+        lib.load()
+        dev = torch.device("cuda:0")
+    for i, case in enumerate(CASES):
+        _run_case(dev, case)
+        print("case", i, "ok", flush=True)
