@@ -57,6 +57,9 @@ struct ConvK {
   int64_t aux2_zoff;
   int chunks_per_tap;
   int nchunks;
+  const void* pre_add;
+  int pre_add_ldc;
+  int ablate;  // perf-debug only (PP_CONV_ABLATE): 1 = no global loads after chunk 0, 2 = no MFMA
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float param) {
@@ -98,6 +101,7 @@ struct EpiCtx {
   OT* out;
   const OT* aux1;
   const OT* aux2;
+  const OT* pre;
 };
 
 // bias + activation(s) + scale + fused epilogue op + channels-last store of 4 consecutive channels
@@ -109,6 +113,7 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
     const int cc = c + r;
     float t = v[r];
     if (e.bias && cc < p.Cout) t += e.bias[cc];
+    if (e.pre && cc < p.Cout) t += to_f32(e.pre[m * p.pre_add_ldc + cc]);
     if (p.act_split > 0 && cc >= p.act_split) {
       t = apply_act(t, p.act2, p.act_param);
     } else {
@@ -327,11 +332,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 
   for (int q = 0; q < p.nchunks; ++q) {
     const int buf = q & 1;
-    if (q + 1 < p.nchunks) load_chunk(q + 1);
+    if (q + 1 < p.nchunks && p.ablate != 1) load_chunk(q + 1);
 
     const T* xs = Xs + buf * BP * LDK + (wp * TP * 16 + frow) * LDK;
     const T* ws = Ws + buf * BC * LDK + (wc * TC * 16 + frow) * LDK;
-    if constexpr (sizeof(T) == 2) {
+    if (p.ablate == 2) {
+    } else if constexpr (sizeof(T) == 2) {
       h8 af[TC], bf[TP];
 #pragma unroll
       for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(ws + a * 16 * LDK + (fgrp ^ fswz) * 8);
@@ -391,6 +397,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   e.out = reinterpret_cast<OT*>(p.out) + (int64_t)z * p.out_zoff;
   e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
+  e.pre = reinterpret_cast<const OT*>(p.pre_add);
   if constexpr (M32) {
     static_for<TP2>([&](auto bi) {
       constexpr int b = decltype(bi)::value;
@@ -500,6 +507,10 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   k.weight = p->weight; k.w_zoff = p->w_zoff;
   k.chunks_per_tap = cpt;
   k.nchunks = cpt * k.kh * k.kw;
+  {
+    static const int ablate = [] { const char* e = getenv("PP_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    k.ablate = ablate;
+  }
   k.Kp = k.nchunks * 32;
   k.bias = reinterpret_cast<const float*>(p->bias); k.bias_zoff = p->bias_zoff;
   k.Cout = (int)p->Cout;
@@ -511,6 +522,8 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   k.epi = p->epi;
   k.aux1 = p->aux1; k.aux1_ldc = (int)p->aux1_ldc; k.aux1_zoff = p->aux1_zoff;
   k.aux2 = p->aux2; k.aux2_ldc = (int)p->aux2_ldc; k.aux2_zoff = p->aux2_zoff;
+  k.pre_add = p->pre_add; k.pre_add_ldc = (int)p->pre_add_ldc;
+  if (p->pre_add && p->Z != 1) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: pre_add with Z > 1");
   const int Z = (int)p->Z;
   if (p->dtype == PP_F16) {
     if (p->out_dtype == PP_F16) return launch_by_cout<half_t, half_t>(stream, k, Z);

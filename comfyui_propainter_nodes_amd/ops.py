@@ -189,12 +189,12 @@ def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, 
 
 
 def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
-           act2=None, act_split=0, out_scale=0.0, epi=None, aux1=None, aux2=None,
+           act2=None, act_split=0, out_scale=0.0, epi=None, aux1=None, aux2=None, pre_add=None,
            in_zoff: list[int] | None = None, out_zoff: int | None = None) -> torch.Tensor:
     """Launch pp_conv2d.  `inputs` are channels-last views (the K segments), `out` a
     channels-last view `[N, Ho, Wo, >=Cout*groups]` that receives the result."""
     L = _lib.current()
-    check_device(*inputs, out, aux1, aux2, spec.weight)
+    check_device(*inputs, out, aux1, aux2, pre_add, spec.weight)
     P = _lib.STRUCTS["pp_conv2d_params"]()
     x0 = inputs[0]
     n, h, w, _, _ = nhwc_view(x0)
@@ -254,6 +254,11 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
         P.aux2 = aux2.data_ptr()
         P.aux2_ldc = nhwc_view(aux2)[4]
         P.aux2_zoff = spec.cout if g > 1 else 0
+    if pre_add is not None:
+        if pre_add.dtype != out.dtype:
+            raise TypeError("pre_add dtype must match out dtype")
+        P.pre_add = pre_add.data_ptr()
+        P.pre_add_ldc = nhwc_view(pre_add)[4]
     if CONV_PROFILE is not None and out.is_cuda:
         flops = 2.0 * n * ho * wo * spec.cout * g * spec.cin_valid * spec.kh * spec.kw
         key = "f16" if x0.dtype == torch.float16 else "f32"

@@ -107,6 +107,9 @@ typedef struct {
   const void* aux2;
   int64_t aux2_ldc;
   int64_t aux2_zoff;
+  const void* pre_add; /* optional [N][Ho][Wo][Cout] (out dtype) added BEFORE the activation: a partial
+                          convolution over constant input channels computed once (RAFT GRU context term) */
+  int64_t pre_add_ldc;
 } pp_conv2d_params;
 
 int32_t pp_conv2d(void* stream, const pp_conv2d_params* p);
