@@ -59,7 +59,6 @@ struct ConvK {
   int nchunks;
   const void* pre_add;
   int pre_add_ldc;
-  int ablate;  // perf-debug only (PP_CONV_ABLATE): 1 = no global loads after chunk 0, 2 = no MFMA
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float param) {
@@ -332,12 +331,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 
   for (int q = 0; q < p.nchunks; ++q) {
     const int buf = q & 1;
-    if (q + 1 < p.nchunks && p.ablate != 1) load_chunk(q + 1);
+    if (q + 1 < p.nchunks) load_chunk(q + 1);
 
     const T* xs = Xs + buf * BP * LDK + (wp * TP * 16 + frow) * LDK;
     const T* ws = Ws + buf * BC * LDK + (wc * TC * 16 + frow) * LDK;
-    if (p.ablate == 2) {
-    } else if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) {
       h8 af[TC], bf[TP];
 #pragma unroll
       for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(ws + a * 16 * LDK + (fgrp ^ fswz) * 8);
@@ -507,10 +505,6 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   k.weight = p->weight; k.w_zoff = p->w_zoff;
   k.chunks_per_tap = cpt;
   k.nchunks = cpt * k.kh * k.kw;
-  {
-    static const int ablate = [] { const char* e = getenv("PP_CONV_ABLATE"); return e ? atoi(e) : 0; }();
-    k.ablate = ablate;
-  }
   k.Kp = k.nchunks * 32;
   k.bias = reinterpret_cast<const float*>(p->bias); k.bias_zoff = p->bias_zoff;
   k.Cout = (int)p->Cout;
