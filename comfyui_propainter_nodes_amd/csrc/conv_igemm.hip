@@ -159,9 +159,9 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
   }
 }
 
-template <typename T, typename OT, int WC, int WP, int TC, int TP, bool M32>
+template <typename T, typename OT, int WC, int WP, int TC, int TP, bool M32, int KC>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
-  constexpr int BK = 32;
+  constexpr int BK = 32;                    // one K chunk = 32 channels of one (tap, segment)
   constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
   constexpr int PPR = BK / EPP;             // pieces per tile row (4 f16, 8 f32)
   constexpr int LDK = BK;                   // LDS row pitch in elements (no padding: XOR-swizzled pieces)
@@ -174,11 +174,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   constexpr int RPP = 256 / PPR;  // rows filled per pass
   constexpr int XPASS = (BP + RPP - 1) / RPP;
   constexpr int WPASS = (BC + RPP - 1) / RPP;
+  constexpr int STAGE = KC * (BP + BC) * LDK;  // elements per pipeline stage (KC chunks per barrier)
   typedef typename Frag<T>::piece piece_t;
 
-  T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);
-  T* Xs = smem;                     // [2][BP][LDK]
-  T* Ws = smem + 2 * BP * LDK;      // [2][BC][LDK]
+  T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);  // [2 stages][KC][ X: BP rows | W: BC rows ][LDK]
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -211,16 +210,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     px0[i] = wo * p.sw - p.pw;
     pn[i] = (int64_t)n * p.H * p.W;
   }
-  // ---- per-thread weight rows -----------------------------------------------------------
   const T* wbase = reinterpret_cast<const T*>(p.weight) + (int64_t)z * p.w_zoff;
 
-  piece_t xreg[XPASS];
-  piece_t wreg[WPASS];
+  piece_t xreg[KC][XPASS];
+  piece_t wreg[KC][WPASS];
 
   // K iterator (wave-uniform): chunk -> (tap ky,kx ; segment ; 32-channel chunk inside the segment).
   // Advanced incrementally (no integer divisions); segment parameters are picked with constant
   // indices only, so the kernel-argument arrays stay in SGPRs instead of being copied to scratch.
-  int it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
+  int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
   const T* it_base = reinterpret_cast<const T*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
   int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0];
   auto select_segment = [&](int seg) {
@@ -235,6 +233,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     }
   };
   auto advance = [&]() {
+    ++it_q;
     if (++it_rem == it_chunks) {
       it_rem = 0;
       if (++it_seg == p.nseg) {
@@ -248,10 +247,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     }
   };
 
-  auto load_chunk = [&](int q) {
+  // global -> registers for the next chunk of the K iterator (zeros past the last chunk)
+  auto load_chunk = [&](auto kci) {
+    constexpr int kc = decltype(kci)::value;
+    const bool live = it_q < p.nchunks;
     const int ky = it_ky, kx = it_kx;
     const int c0 = it_rem * BK + pc * EPP;
-    const bool cvalid = c0 < it_C;
+    const bool cvalid = live && (c0 < it_C);
     const T* sbase = it_base;
     const int ldc = it_ldc;
 #pragma unroll
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         const T* src = sbase + (pn[i] + (int64_t)y * p.W + x) * ldc + c0;
         v = *reinterpret_cast<const piece_t*>(src);
       }
-      xreg[i] = v;
+      xreg[kc][i] = v;
     }
 #pragma unroll
     for (int i = 0; i < WPASS; ++i) {
@@ -281,28 +283,32 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
       piece_t v;
 #pragma unroll
       for (int e = 0; e < EPP; ++e) v[e] = (T)0;
-      if (r < BC && co < p.Cout) {
-        const T* src = wbase + (int64_t)co * p.Kp + (int64_t)q * BK + pc * EPP;
+      if (live && r < BC && co < p.Cout) {
+        const T* src = wbase + (int64_t)co * p.Kp + (int64_t)it_q * BK + pc * EPP;
         v = *reinterpret_cast<const piece_t*>(src);
       }
-      wreg[i] = v;
+      wreg[kc][i] = v;
     }
-    advance();
+    if (live) advance();
   };
+  auto load_stage = [&]() { static_for<KC>([&](auto kci) { load_chunk(kci); }); };
 
-  auto store_chunk = [&](int buf) {
-    T* xs = Xs + buf * BP * LDK;
-    T* ws = Ws + buf * BC * LDK;
+  auto store_stage = [&](int buf) {
+    static_for<KC>([&](auto kci) {
+      constexpr int kc = decltype(kci)::value;
+      T* xs = smem + buf * STAGE + kc * (BP + BC) * LDK;
+      T* ws = xs + BP * LDK;
 #pragma unroll
-    for (int i = 0; i < XPASS; ++i) {
-      const int r = row0 + i * RPP;
-      if (r < BP) *reinterpret_cast<piece_t*>(xs + r * LDK + (pc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * EPP) = xreg[i];
-    }
+      for (int i = 0; i < XPASS; ++i) {
+        const int r = row0 + i * RPP;
+        if (r < BP) *reinterpret_cast<piece_t*>(xs + r * LDK + (pc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * EPP) = xreg[kc][i];
+      }
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) {
-      const int r = row0 + i * RPP;
-      if (r < BC) *reinterpret_cast<piece_t*>(ws + r * LDK + (pc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * EPP) = wreg[i];
-    }
+      for (int i = 0; i < WPASS; ++i) {
+        const int r = row0 + i * RPP;
+        if (r < BC) *reinterpret_cast<piece_t*>(ws + r * LDK + (pc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * EPP) = wreg[kc][i];
+      }
+    });
   };
 
   f4 acc[TC][TP];
@@ -325,65 +331,73 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   const int fgrp = lane >> 4;
   const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;  // tile rows are multiples of 16 apart: swizzle depends on frow only
 
-  load_chunk(0);
-  store_chunk(0);
+  const int nstages = (p.nchunks + KC - 1) / KC;
+  load_stage();
+  store_stage(0);
   __syncthreads();
 
-  for (int q = 0; q < p.nchunks; ++q) {
-    const int buf = q & 1;
-    if (q + 1 < p.nchunks) load_chunk(q + 1);
+  for (int qs = 0; qs < nstages; ++qs) {
+    const int buf = qs & 1;
+    if (qs + 1 < nstages) load_stage();
 
-    const T* xs = Xs + buf * BP * LDK + (wp * TP * 16 + frow) * LDK;
-    const T* ws = Ws + buf * BC * LDK + (wc * TC * 16 + frow) * LDK;
-    if constexpr (sizeof(T) == 2) {
-      h8 af[TC], bf[TP];
+    static_for<KC>([&](auto kci) {
+      constexpr int kc = decltype(kci)::value;
+      const T* xt = smem + buf * STAGE + kc * (BP + BC) * LDK;
+      const T* wt = xt + BP * LDK;
+      if constexpr (sizeof(T) == 2) {
+        const T* xs = xt + (wp * TP * 16 + frow) * LDK;
+        const T* ws = wt + (wc * TC * 16 + frow) * LDK;
+        h8 af[TC], bf[TP];
 #pragma unroll
-      for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(ws + a * 16 * LDK + (fgrp ^ fswz) * 8);
+        for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(ws + a * 16 * LDK + (fgrp ^ fswz) * 8);
 #pragma unroll
-      for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const h8*>(xs + b * 16 * LDK + (fgrp ^ fswz) * 8);
-#pragma unroll
-      for (int a = 0; a < TC; ++a)
-#pragma unroll
-        for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(af[a], bf[b], acc[a][b]);
-    } else if constexpr (M32) {
-      const T* xs32 = Xs + buf * BP * LDK + (wp * TP * 16 + r32) * LDK;
-      const T* ws32 = Ws + buf * BC * LDK + (wc * TC * 16 + r32) * LDK;
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {  // 8 k per sub-chunk: lane half kh32 supplies k = 4*kh32 + j at step j
-        f4 af[TC2], bf[TP2];
-#pragma unroll
-        for (int a = 0; a < TC2; ++a)
-          af[a] = *reinterpret_cast<const f4*>(ws32 + a * 32 * LDK + ((sub * 2 + kh32) ^ (r32 & 7)) * 4);
-#pragma unroll
-        for (int b = 0; b < TP2; ++b)
-          bf[b] = *reinterpret_cast<const f4*>(xs32 + b * 32 * LDK + ((sub * 2 + kh32) ^ (r32 & 7)) * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int a = 0; a < TC2; ++a)
-#pragma unroll
-            for (int b = 0; b < TP2; ++b) acc32[a][b] = mfma_32x32x2_f32(af[a][j], bf[b][j], acc32[a][b]);
-      }
-    } else {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        f4 af[TC], bf[TP];
+        for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const h8*>(xs + b * 16 * LDK + (fgrp ^ fswz) * 8);
 #pragma unroll
         for (int a = 0; a < TC; ++a)
-          af[a] = *reinterpret_cast<const f4*>(ws + a * 16 * LDK + ((sub * 4 + fgrp) ^ fswz) * 4);
 #pragma unroll
-        for (int b = 0; b < TP; ++b)
-          bf[b] = *reinterpret_cast<const f4*>(xs + b * 16 * LDK + ((sub * 4 + fgrp) ^ fswz) * 4);
+          for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(af[a], bf[b], acc[a][b]);
+      } else if constexpr (M32) {
+        const T* xs32 = xt + (wp * TP * 16 + r32) * LDK;
+        const T* ws32 = wt + (wc * TC * 16 + r32) * LDK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int sub = 0; sub < 4; ++sub) {  // 8 k per sub-chunk: lane half kh32 supplies k = 4*kh32 + j at step j
+          f4 af[TC2], bf[TP2];
+#pragma unroll
+          for (int a = 0; a < TC2; ++a)
+            af[a] = *reinterpret_cast<const f4*>(ws32 + a * 32 * LDK + ((sub * 2 + kh32) ^ (r32 & 7)) * 4);
+#pragma unroll
+          for (int b = 0; b < TP2; ++b)
+            bf[b] = *reinterpret_cast<const f4*>(xs32 + b * 32 * LDK + ((sub * 2 + kh32) ^ (r32 & 7)) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < TC2; ++a)
+#pragma unroll
+              for (int b = 0; b < TP2; ++b) acc32[a][b] = mfma_32x32x2_f32(af[a][j], bf[b][j], acc32[a][b]);
+        }
+      } else {
+        const T* xs = xt + (wp * TP * 16 + frow) * LDK;
+        const T* ws = wt + (wc * TC * 16 + frow) * LDK;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          f4 af[TC], bf[TP];
 #pragma unroll
           for (int a = 0; a < TC; ++a)
+            af[a] = *reinterpret_cast<const f4*>(ws + a * 16 * LDK + ((sub * 4 + fgrp) ^ fswz) * 4);
 #pragma unroll
-            for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x4_f32(af[a][j], bf[b][j], acc[a][b]);
+          for (int b = 0; b < TP; ++b)
+            bf[b] = *reinterpret_cast<const f4*>(xs + b * 16 * LDK + ((sub * 4 + fgrp) ^ fswz) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < TC; ++a)
+#pragma unroll
+              for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x4_f32(af[a][j], bf[b][j], acc[a][b]);
+        }
       }
-    }
+    });
 
-    if (q + 1 < p.nchunks) store_chunk(buf ^ 1);
+    if (qs + 1 < nstages) store_stage(buf ^ 1);
     __syncthreads();
   }
 
@@ -427,13 +441,15 @@ template <typename T, typename OT, int WC, int WP, int TC, int TP>
 static int launch_cfg(void* stream, const ConvK& k, int Z) {
   // f32: 32x32x2 MFMA tiles whenever the per-wave tile is a multiple of 32x32
   constexpr bool M32 = (sizeof(T) == 4) && (TC % 2 == 0) && (TP % 2 == 0);
+  // f16: two 32-channel chunks per barrier (an MFMA phase of 16 x 16x16x32 is too short to amortise one)
+  constexpr int KC = (sizeof(T) == 2) ? 2 : 1;
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
   constexpr int LDK = 32;
-  const size_t smem = (size_t)2 * (BC + BP) * LDK * sizeof(T);
+  const size_t smem = (size_t)2 * KC * (BC + BP) * LDK * sizeof(T);
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
-  pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32>), smem);
-  PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32>), grid, dim3(256), smem, stream, k);
+  pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem);
+  PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), grid, dim3(256), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }
 
