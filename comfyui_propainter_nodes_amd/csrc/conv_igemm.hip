@@ -441,14 +441,16 @@ template <typename T, typename OT, int WC, int WP, int TC, int TP>
 static int launch_cfg(void* stream, const ConvK& k, int Z) {
   // f32: 32x32x2 MFMA tiles whenever the per-wave tile is a multiple of 32x32
   constexpr bool M32 = (sizeof(T) == 4) && (TC % 2 == 0) && (TP % 2 == 0);
-  // f16: two 32-channel chunks per barrier (an MFMA phase of 16 x 16x16x32 is too short to amortise one)
-  constexpr int KC = (sizeof(T) == 2) ? 2 : 1;
+  // KC = 32-channel chunks staged per barrier.  Measured on MI355X (r01): KC = 2 for f16 halves the barriers
+  // but doubles LDS per work-group (2 instead of 3-4 resident work-groups per CU) and is a net loss.
+  constexpr int KC = 1;
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
   constexpr int LDK = 32;
   const size_t smem = (size_t)2 * KC * (BC + BP) * LDK * sizeof(T);
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
-  pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem);
+  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem), true);
+  (void)lds_ok;  // once per instantiation, not per launch
   PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), grid, dim3(256), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }
