@@ -193,15 +193,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 
   // ---- per-thread pixel rows of the X tile --------------------------------------------
   int py0[XPASS], px0[XPASS];
-  int64_t pn[XPASS];
-  bool pvalid[XPASS];
+  int64_t pn[XPASS], prow[XPASS];
 #pragma unroll
   for (int i = 0; i < XPASS; ++i) {
     const int r = row0 + i * RPP;
     const int64_t m = p_base + r;
-    const bool ok = (r < BP) && (m < p.M);
-    pvalid[i] = ok;
-    const int64_t mm = ok ? m : 0;
+    const int64_t mm = (r < BP && m < p.M) ? m : p.M - 1;  // rows past M: clamped, results never stored
     const int wo = (int)(mm % p.Wo);
     const int64_t t = mm / p.Wo;
     const int ho = (int)(t % p.Ho);
@@ -209,8 +206,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     py0[i] = ho * p.sh - p.ph;
     px0[i] = wo * p.sw - p.pw;
     pn[i] = (int64_t)n * p.H * p.W;
+    prow[i] = pn[i] + (int64_t)py0[i] * p.W + px0[i];  // pixel index of tap (0,0); may be "negative" for padded taps
   }
+  // ---- per-thread weight rows (rows past Cout: clamped, results never stored) ------------
   const T* wbase = reinterpret_cast<const T*>(p.weight) + (int64_t)z * p.w_zoff;
+  const T* wrow[WPASS];
+#pragma unroll
+  for (int i = 0; i < WPASS; ++i) {
+    const int co = c_base + row0 + i * RPP;
+    wrow[i] = wbase + (int64_t)(co < p.Cout ? co : p.Cout - 1) * p.Kp + pc * EPP;
+  }
 
   piece_t xreg[KC][XPASS];
   piece_t wreg[KC][WPASS];
@@ -247,45 +252,45 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     }
   };
 
-  // global -> registers for the next chunk of the K iterator (zeros past the last chunk)
+  // global -> registers for the next chunk of the K iterator.  Every load is UNCONDITIONAL (a predicated
+  // load costs an exec-mask branch per piece): out-of-image taps / padded channels read a safe address and
+  // are zeroed by a select; tile rows past M / Cout read a clamped row, their results are never stored.
   auto load_chunk = [&](auto kci) {
     constexpr int kc = decltype(kci)::value;
-    const bool live = it_q < p.nchunks;
-    const int ky = it_ky, kx = it_kx;
+    const bool live = (KC == 1) || (it_q < p.nchunks);
     const int c0 = it_rem * BK + pc * EPP;
     const bool cvalid = live && (c0 < it_C);
     const T* sbase = it_base;
     const int ldc = it_ldc;
+    const int dy = it_ky * p.dh, dx = it_kx * p.dw;
+    const int64_t tapoff = (int64_t)dy * p.W + dx;  // wave-uniform pixel offset of this tap
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
-      int y = py0[i] + ky * p.dh;
-      int x = px0[i] + kx * p.dw;
-      bool ok = pvalid[i] && cvalid;
+      const int y = py0[i] + dy, x = px0[i] + dx;
+      bool ok = cvalid;
+      int64_t pix;
       if (p.pad_mode == PP_PAD_REPLICATE) {
-        y = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
-        x = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
+        const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
+        const int xc = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
+        pix = pn[i] + (int64_t)yc * p.W + xc;
       } else {
         ok = ok && (y >= 0) && (y < p.H) && (x >= 0) && (x < p.W);
+        pix = prow[i] + tapoff;
       }
-      piece_t v;
+      const T* src = ok ? sbase + pix * ldc + c0 : sbase;
+      piece_t v = *reinterpret_cast<const piece_t*>(src);
+      if (!ok) {
 #pragma unroll
-      for (int e = 0; e < EPP; ++e) v[e] = (T)0;
-      if (ok) {
-        const T* src = sbase + (pn[i] + (int64_t)y * p.W + x) * ldc + c0;
-        v = *reinterpret_cast<const piece_t*>(src);
+        for (int e = 0; e < EPP; ++e) v[e] = (T)0;
       }
       xreg[kc][i] = v;
     }
 #pragma unroll
     for (int i = 0; i < WPASS; ++i) {
-      const int r = row0 + i * RPP;
-      const int co = c_base + r;
-      piece_t v;
+      piece_t v = *reinterpret_cast<const piece_t*>(wrow[i] + (int64_t)(live ? it_q : 0) * BK);
+      if (KC > 1 && !live) {
 #pragma unroll
-      for (int e = 0; e < EPP; ++e) v[e] = (T)0;
-      if (live && r < BC && co < p.Cout) {
-        const T* src = wbase + (int64_t)co * p.Kp + (int64_t)it_q * BK + pc * EPP;
-        v = *reinterpret_cast<const piece_t*>(src);
+        for (int e = 0; e < EPP; ++e) v[e] = (T)0;
       }
       wreg[kc][i] = v;
     }
