@@ -208,21 +208,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     pn[i] = (int64_t)n * p.H * p.W;
     prow[i] = pn[i] + (int64_t)py0[i] * p.W + px0[i];  // pixel index of tap (0,0); may be "negative" for padded taps
   }
-  // bit t of tapmask[i] = tap t = ky*kw+kx of row i lies inside the image (zero padding); <= 64 taps
-  uint64_t tapmask[XPASS];
-  const bool use_mask = (p.kh * p.kw <= 64) && (p.pad_mode != PP_PAD_REPLICATE);
-#pragma unroll
-  for (int i = 0; i < XPASS; ++i) {
-    uint64_t mk = 0;
-    if (use_mask) {
-      for (int ky = 0; ky < p.kh; ++ky)
-        for (int kx = 0; kx < p.kw; ++kx) {
-          const int y = py0[i] + ky * p.dh, x = px0[i] + kx * p.dw;
-          if (y >= 0 && y < p.H && x >= 0 && x < p.W) mk |= (uint64_t)1 << (ky * p.kw + kx);
-        }
-    }
-    tapmask[i] = mk;
-  }
   // ---- per-thread weight rows (rows past Cout: clamped, results never stored) ------------
   const T* wbase = reinterpret_cast<const T*>(p.weight) + (int64_t)z * p.w_zoff;
   const T* wrow[WPASS];
@@ -241,7 +226,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
   const T* it_base = reinterpret_cast<const T*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
   int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0];
-  const T* rowptr[XPASS];  // address of (tap (0,0), channel pc*EPP) of each tile row in the CURRENT segment
   auto select_segment = [&](int seg) {
 #pragma unroll
     for (int s = 0; s < PP_MAX_SEG; ++s) {
@@ -252,10 +236,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         it_chunks = p.seg_chunks[s];
       }
     }
-#pragma unroll
-    for (int i = 0; i < XPASS; ++i) rowptr[i] = it_base + prow[i] * it_ldc + pc * EPP;
   };
-  select_segment(0);
   auto advance = [&]() {
     ++it_q;
     if (++it_rem == it_chunks) {
@@ -282,28 +263,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     const T* sbase = it_base;
     const int ldc = it_ldc;
     const int dy = it_ky * p.dh, dx = it_kx * p.dw;
-    const int tap = it_ky * p.kw + it_kx;
-    // wave-uniform element offset of (this tap, this 32-channel chunk) relative to rowptr[]
-    const int64_t uoff = ((int64_t)dy * p.W + dx) * ldc + it_rem * BK;
+    const int64_t tapoff = (int64_t)dy * p.W + dx;  // wave-uniform pixel offset of this tap
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
+      const int y = py0[i] + dy, x = px0[i] + dx;
       bool ok = cvalid;
-      const T* src;
+      int64_t pix;
       if (p.pad_mode == PP_PAD_REPLICATE) {
-        const int y = py0[i] + dy, x = px0[i] + dx;
         const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
         const int xc = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
-        src = sbase + (pn[i] + (int64_t)yc * p.W + xc) * ldc + c0;
+        pix = pn[i] + (int64_t)yc * p.W + xc;
       } else {
-        if (use_mask) {
-          ok = ok && ((tapmask[i] >> tap) & 1);
-        } else {
-          const int y = py0[i] + dy, x = px0[i] + dx;
-          ok = ok && (y >= 0) && (y < p.H) && (x >= 0) && (x < p.W);
-        }
-        src = rowptr[i] + uoff;
+        ok = ok && (y >= 0) && (y < p.H) && (x >= 0) && (x < p.W);
+        pix = prow[i] + tapoff;
       }
-      if (!ok) src = sbase;
+      const T* src = ok ? sbase + pix * ldc + c0 : sbase;
       piece_t v = *reinterpret_cast<const piece_t*>(src);
       if (!ok) {
 #pragma unroll
