@@ -1,0 +1,25 @@
+"""Whole stages executed on CPU under the kernel emulator (tests/emu) against the oracle -- the same host
+schedulers and the same kernel sources that run on the MI355X, at sizes the emulator finishes in a minute.
+(The GPU suite repeats these at real sizes through the gfx950 library.)"""
+import torch
+import torch.nn.functional as F
+
+from comfyui_propainter_nodes_amd import rfc, weights
+from oracle import rfc as OC
+
+
+def test_flow_completion_stage_under_emulation(emu_lib):
+    sds = weights.synth_state_dicts(0)
+    T, H, W = 3, 32, 40
+    g = torch.Generator().manual_seed(5)
+    flows = torch.randn(2, T, H, W, 2, generator=g) * 2
+    masks = torch.zeros(T + 1, H, W, dtype=torch.uint8)
+    masks[:, H // 3:2 * H // 3, W // 4:3 * W // 4] = 1
+    out = rfc.FlowCompleter(sds["rfc"], "cpu")(flows, masks)
+    of, ob = flows[0].permute(0, 3, 1, 2)[None], flows[1].permute(0, 3, 1, 2)[None]
+    m = masks.float()[None, :, None]
+    with torch.no_grad():
+        ref = OC.combine_flow((of, ob), OC.forward_bidirect_flow(sds["rfc"], (of, ob), m), m)
+    for d in (0, 1):
+        err = (out[d].permute(0, 3, 1, 2) - ref[d][0]).abs().max().item()
+        assert err < 2e-2, err  # f16 activations vs fp32 oracle, flows of a few px
