@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   // 16-byte piece p of tile row r is stored at piece p ^ swz(r): conflict-free for the ds_read_b128
   // lane groups AND the ds_write_b128 groups of gfx950 (f16: 4 pieces/row, f32: 8 pieces/row)
   constexpr int SWZ_MASK = PPR - 1;
-  constexpr int SWZ_SHIFT = (sizeof(T) == 2) ? 1 : 0;
+  constexpr int SWZ_SHIFT = 1;  // swz(r) = (r >> 1) & (PPR - 1): also conflict-free for the 32-row M32 read pattern
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
   constexpr int RPP = 256 / PPR;  // rows filled per pass
@@ -369,10 +369,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
           f4 af[TC2], bf[TP2];
 #pragma unroll
           for (int a = 0; a < TC2; ++a)
-            af[a] = *reinterpret_cast<const f4*>(ws32 + a * 32 * LDK + ((sub * 2 + kh32) ^ (r32 & 7)) * 4);
+            af[a] = *reinterpret_cast<const f4*>(ws32 + a * 32 * LDK + ((sub * 2 + kh32) ^ ((r32 >> 1) & 7)) * 4);
 #pragma unroll
           for (int b = 0; b < TP2; ++b)
-            bf[b] = *reinterpret_cast<const f4*>(xs32 + b * 32 * LDK + ((sub * 2 + kh32) ^ (r32 & 7)) * 4);
+            bf[b] = *reinterpret_cast<const f4*>(xs32 + b * 32 * LDK + ((sub * 2 + kh32) ^ ((r32 >> 1) & 7)) * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
