@@ -17,7 +17,10 @@ __device__ __forceinline__ float warp_coord(int pos, float f, int size) {
   const float g = (float)pos + f;
   const float d = (float)(size - 1 > 1 ? size - 1 : 1);
   const float n = 2.0f * g / d - 1.0f;
-  return (n + 1.0f) * ((float)(size - 1) / 2.0f);
+  const float r = (n + 1.0f) * ((float)(size - 1) / 2.0f);
+  // non-finite / absurd coordinates (NaN or Inf flows) are mapped far outside the image: every later
+  // float->int conversion stays defined and the sample is simply "out of range" (zeros)
+  return (fabsf(r) < 1.0e8f) ? r : -1.0e8f;
 }
 
 // bilinear sample of a C-channel fp32 pixel array (pitch ldc) with zero padding

@@ -194,8 +194,10 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
   const float fx = k.flow[pix * k.flow_ldc + 0];
   const float fy = k.flow[pix * k.flow_ldc + 1];
   const float scale = 1.f / (float)(1 << lvl);
-  const float cx = ((float)px + fx) * scale + (float)(i - 4);
-  const float cy = ((float)py + fy) * scale + (float)(j - 4);
+  float cx = ((float)px + fx) * scale + (float)(i - 4);
+  float cy = ((float)py + fy) * scale + (float)(j - 4);
+  if (!(fabsf(cx) < 1.0e8f)) cx = -1.0e8f;  // NaN / Inf flow: out of range, conversions stay defined
+  if (!(fabsf(cy) < 1.0e8f)) cy = -1.0e8f;
   const int H = k.ph[lvl], W = k.pw[lvl];
   const float* plane = k.pyr[lvl] + pix * (int64_t)H * W;
   k.out[pix * k.out_ldc + ch] = sample_plane(plane, H, W, cx, cy);

@@ -46,8 +46,10 @@ __global__ void __launch_bounds__(256) deform_cols_kernel(const DeformK k) {
     dx += f[0];
     dy += f[1];
   }
-  const float py = (float)(y - 1 + tap / 3) + dy;
-  const float px = (float)(x - 1 + tap % 3) + dx;
+  float py = (float)(y - 1 + tap / 3) + dy;
+  float px = (float)(x - 1 + tap % 3) + dx;
+  if (!(fabsf(py) < 1.0e8f)) py = -1.0e8f;  // NaN / Inf offsets: out of range, float->int conversions stay defined
+  if (!(fabsf(px) < 1.0e8f)) px = -1.0e8f;
   T* dst = reinterpret_cast<T*>(k.cols) + pix * (int64_t)(9 * k.Cin) + tap * k.Cin + g * k.cg;
   // source slab of this group's channels
   const int c0 = g * k.cg;

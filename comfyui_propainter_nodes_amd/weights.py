@@ -63,6 +63,10 @@ def _synth_tensor(name: str, shape: list[int], g: torch.Generator) -> torch.Tens
     gain = 1.0 if len(shape) == 2 else 1.4
     if "conv_offset.6" in name:
         gain = 0.5
+    if ".backbone." in name and name.endswith(".2.weight") or name.endswith("fuse.2.weight"):
+        # residual branches of the two recurrences: contractive, so that a synthetic (untrained) net does not
+        # grow geometrically over ~80-160 propagation steps and overflow f16 (trained checkpoints do not)
+        gain = 0.3
     if "flow_head.conv2" in name:  # keep the synthetic RAFT well-conditioned (sub-pixel updates per iteration)
         gain = 0.1
     if name.startswith("decoder.6"):  # keep the synthetic generator's tanh un-saturated

@@ -1,0 +1,62 @@
+"""Run one BASELINE.json config end to end on the MI355X and print frames/s + stage times + peak memory."""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from comfyui_propainter_nodes_amd import image_utils, lib, nodes, pipeline, synth, weights  # noqa: E402
+
+CONFIGS = {
+    2: dict(T=80, H=360, W=640, nl=10, rs=10, sv=80, iters=20, outpaint=None),
+    3: dict(T=80, H=360, W=640, nl=10, rs=10, sv=80, iters=20, outpaint=(1.2, 1.0)),
+    5: dict(T=160, H=720, W=1280, nl=20, rs=10, sv=80, iters=20, outpaint=None),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--size", type=str, default="")
+    a = ap.parse_args()
+    c = dict(CONFIGS[a.config])
+    if a.frames:
+        c["T"] = a.frames
+    if a.size:
+        c["W"], c["H"] = [int(v) for v in a.size.split("x")]
+    lib.load()
+    dev = torch.device("cuda:0")
+    os.environ["PP_TIMING"] = "1"
+    sds, prov = weights.get_state_dicts(0)
+    models = pipeline.models_from_state_dicts(sds, dev)
+    image, mask = synth.synthetic_clip(c["T"], c["H"], c["W"])
+    u8 = image_utils.image_to_uint8_frames(image)
+    if c["outpaint"]:
+        oc = image_utils.ImageOutpaintConfig(c["W"], c["H"], 5, 8, (c["W"], c["H"]), c["T"], *c["outpaint"])
+        fr, fm, md = image_utils.extrapolation(u8, oc)
+        size = oc.outpaint_size
+    else:
+        ic = image_utils.ImageConfig(c["W"], c["H"], 5, 8, (c["W"], c["H"]), c["T"])
+        fr, fm, md = image_utils.prepare_frames_and_masks(u8, mask, ic)
+        size = ic.process_size
+    cfg = pipeline.ProPainterConfig(c["rs"], c["nl"], c["sv"], c["iters"], "enable", c["T"], dev, size)
+    args = (models, torch.from_numpy(fr).to(dev), torch.from_numpy(fm).to(dev), torch.from_numpy(md).to(dev), cfg)
+    for rep in range(a.reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = pipeline.run_inpainting(*args, to_host=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": a.config, "frames": c["T"], "size": list(size), "seconds": round(dt, 3),
+                          "frames_per_s": round(c["T"] / dt, 2), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                          "out_mean": float(out.float().mean())}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
