@@ -22,7 +22,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture()
 def emu_lib():
     """Build (if needed) and load the x86 emulation of the kernel sources. TEST ONLY."""
     from comfyui_propainter_nodes_amd import build, lib
