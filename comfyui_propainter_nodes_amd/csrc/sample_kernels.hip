@@ -75,6 +75,29 @@ __global__ void __launch_bounds__(256) deform_cols_kernel(const DeformK k) {
   const T* r01 = r00 + ldc;
   const T* r10 = r00 + (int64_t)k.W * ldc;
   const T* r11 = r10 + ldc;
+  if constexpr (sizeof(T) == 2) {
+    if ((k.cg & 7) == 0) {  // 16-byte pieces (channels-last rows are 16-byte aligned: C, ldc multiples of 8)
+      for (int c = 0; c < k.cg; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        auto acc = [&](const T* r, float wgt) {
+          const h8 q = *reinterpret_cast<const h8*>(r + c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += wgt * (float)q[e];
+        };
+        if (y0ok && x0ok) acc(r00, w00);
+        if (y0ok && x1ok) acc(r01, w01);
+        if (y1ok && x0ok) acc(r10, w10);
+        if (y1ok && x1ok) acc(r11, w11);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+        *reinterpret_cast<h8*>(dst + c) = o;
+      }
+      return;
+    }
+  }
   for (int c = 0; c < k.cg; ++c) {
     float v = 0.f;
     if (y0ok && x0ok) v += w00 * to_f32(r00[c]);
@@ -113,6 +136,41 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ i
   const float v11 = to_f32(base[((int64_t)y1 * W + x1) * in_ldc]);
   const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
   out[opix * out_ldc + c] = from_f32<T>(v);
+}
+
+// 8 channels per thread (f16, C % 8 == 0): 16-byte loads / stores
+__global__ void __launch_bounds__(256) upsample2x_h8_kernel(const half_t* __restrict__ in, int in_ldc,
+                                                            half_t* __restrict__ out, int out_ldc, int H, int W,
+                                                            int C, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over N*2H*2W*(C/8)
+  if (idx >= total) return;
+  const int pieces = C / 8;
+  const int pc = (int)(idx % pieces);
+  const int64_t opix = idx / pieces;
+  const int Wo = 2 * W, Ho = 2 * H;
+  const int xo = (int)(opix % Wo);
+  const int64_t t = opix / Wo;
+  const int yo = (int)(t % Ho);
+  const int64_t n = t / Ho;
+  const float sy = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const float fy = sy * (float)yo, fx = sx * (float)xo;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const half_t* base = in + n * (int64_t)H * W * in_ldc + pc * 8;
+  const h8 v00 = *reinterpret_cast<const h8*>(base + ((int64_t)y0 * W + x0) * in_ldc);
+  const h8 v01 = *reinterpret_cast<const h8*>(base + ((int64_t)y0 * W + x1) * in_ldc);
+  const h8 v10 = *reinterpret_cast<const h8*>(base + ((int64_t)y1 * W + x0) * in_ldc);
+  const h8 v11 = *reinterpret_cast<const h8*>(base + ((int64_t)y1 * W + x1) * in_ldc);
+  h8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = (1.f - ly) * ((1.f - lx) * (float)v00[e] + lx * (float)v01[e]) +
+                    ly * ((1.f - lx) * (float)v10[e] + lx * (float)v11[e]);
+    o[e] = (half_t)v;
+  }
+  *reinterpret_cast<h8*>(out + opix * out_ldc + pc * 8) = o;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -185,7 +243,12 @@ extern "C" int32_t pp_upsample2x(void* stream, const pp_upsample2x_params* p) {
   if (!p || !p->in || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_upsample2x: null argument");
   const int64_t total = p->N * 4 * p->H * p->W * p->C;
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_upsample2x: empty problem");
-  if (p->dtype == PP_F16) {
+  if (p->dtype == PP_F16 && (p->C % 8) == 0 && (p->in_ldc % 8) == 0 && (p->out_ldc % 8) == 0 &&
+      ((reinterpret_cast<uintptr_t>(p->in) | reinterpret_cast<uintptr_t>(p->out)) & 15) == 0) {
+    const int64_t tv = total / 8;
+    PP_LAUNCH(upsample2x_h8_kernel, dim3(nblk(tv)), dim3(256), 0, stream, (const half_t*)p->in, (int)p->in_ldc,
+              (half_t*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, tv);
+  } else if (p->dtype == PP_F16) {
     PP_LAUNCH((upsample2x_kernel<half_t>), dim3(nblk(total)), dim3(256), 0, stream, (const half_t*)p->in,
               (int)p->in_ldc, (half_t*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, total);
   } else if (p->dtype == PP_F32) {
