@@ -150,12 +150,17 @@ def main():
     ops.CONV_PROFILE = None
     dom = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
     roofline = None
+    traffic = None
+    tfile = ROOT / "profiles" / "r01_traffic.json"
+    if dom == "f32" and tfile.exists():  # PMC passes cannot run inside bench.py: the committed rocprofv3 result
+        traffic = json.loads(tfile.read_text())["hbm_bytes_per_launch"]
     if dom:
         d = prof[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         roofline = {"kernel": f"conv_igemm_kernel<{dom}> (pp_conv2d, MFMA implicit GEMM)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dom], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dom], 4),
-                    "traffic": None, "launches": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / d["n"], 2),
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
+                    "algorithmic_bytes_per_launch": d["bytes"] / d["n"], "launches": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / d["n"], 2),
                     "flops_per_launch": d["flops"] / d["n"], "share_of_step_ms": round(d["ms"], 1),
                     "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 1), "launches": v["n"]}
                               for k, v in prof.items() if k != dom}}

@@ -41,20 +41,21 @@ class ConvProfile:
         self.records = []
         self.detailed = detailed
 
-    def launch(self, key: str, flops: float, fn) -> None:
+    def launch(self, key: str, flops: float, fn, nbytes: float = 0.0) -> None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.records.append((key, flops, e0, e1))
+        self.records.append((key, flops, e0, e1, nbytes))
 
     def summary(self) -> dict:
         torch.cuda.synchronize()
         out: dict = {}
-        for key, flops, e0, e1 in self.records:
-            d = out.setdefault(key, {"ms": 0.0, "flops": 0.0, "n": 0})
+        for key, flops, e0, e1, nbytes in self.records:
+            d = out.setdefault(key, {"ms": 0.0, "flops": 0.0, "n": 0, "bytes": 0.0})
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["n"] += 1
         return out
 
@@ -264,8 +265,12 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
         key = "f16" if x0.dtype == torch.float16 else "f32"
         if CONV_PROFILE.detailed:
             key += f"|k{spec.kh}x{spec.kw} cin{spec.cin_valid} cout{spec.cout} g{g} M{n * ho * wo}"
+        # algorithmic HBM bytes: every input / weight / epilogue operand read once, the output written once
+        esz, osz = x0.element_size(), out.element_size()
+        nbytes = (n * h * w * sum(spec.seg_channels) * g * esz + spec.weight.numel() * esz
+                  + n * ho * wo * spec.cout * g * osz * (1 + sum(t is not None for t in (aux1, aux2, pre_add))))
         CONV_PROFILE.launch(key, flops,
-                            lambda: L.call("pp_conv2d", stream_handle(out), P))
+                            lambda: L.call("pp_conv2d", stream_handle(out), P), nbytes)
     else:
         L.call("pp_conv2d", stream_handle(out), P)
     return out
