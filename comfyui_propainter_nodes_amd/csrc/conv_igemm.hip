@@ -175,6 +175,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   constexpr int XPASS = (BP + RPP - 1) / RPP;
   constexpr int WPASS = (BC + RPP - 1) / RPP;
   constexpr int STAGE = KC * (BP + BC) * LDK;  // elements per pipeline stage (KC chunks per barrier)
+  // DMA: tiles staged with global_load_lds (no VGPR round trip, no ds_write) when every wave-instruction of the
+  // staging pass covers whole tile rows of both tiles; otherwise global -> VGPR -> LDS.
+  constexpr bool DMA = (BP % RPP == 0) && (BC % RPP == 0);
   typedef typename Frag<T>::piece piece_t;
 
   T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);  // [2 stages][KC][ X: BP rows | W: BC rows ][LDK]
@@ -188,8 +191,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   const int64_t p_base = (int64_t)blockIdx.x * BP;
   const int c_base = (int)blockIdx.y * BC;
 
-  const int pc = tid % PPR;   // piece column inside a tile row
+  const int pc = tid % PPR;   // LDS piece slot inside a tile row (lane-linear: slot index == tid within a pass)
   const int row0 = tid / PPR;
+  // LDS slot (r, pc) holds global piece pc ^ swz(r); RPP is a multiple of 16, so swz(r) = swz(row0) for every pass
+  const int pcs = pc ^ ((row0 >> SWZ_SHIFT) & SWZ_MASK);
 
   // ---- per-thread pixel rows of the X tile --------------------------------------------
   int py0[XPASS], px0[XPASS];
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 #pragma unroll
   for (int i = 0; i < WPASS; ++i) {
     const int co = c_base + row0 + i * RPP;
-    wrow[i] = wbase + (int64_t)(co < p.Cout ? co : p.Cout - 1) * p.Kp + pc * EPP;
+    wrow[i] = wbase + (int64_t)(co < p.Cout ? co : p.Cout - 1) * p.Kp + pcs * EPP;
   }
 
   piece_t xreg[KC][XPASS];
@@ -258,7 +263,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   auto load_chunk = [&](auto kci) {
     constexpr int kc = decltype(kci)::value;
     const bool live = (KC == 1) || (it_q < p.nchunks);
-    const int c0 = it_rem * BK + pc * EPP;
+    const int c0 = it_rem * BK + pcs * EPP;
     const bool cvalid = live && (c0 < it_C);
     const T* sbase = it_base;
     const int ldc = it_ldc;
@@ -298,6 +303,40 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   };
   auto load_stage = [&]() { static_for<KC>([&](auto kci) { load_chunk(kci); }); };
 
+  // DMA variant of load_chunk + store: the same source addresses, but every wave-instruction copies 64 x 16 bytes
+  // straight into the lane-linear LDS image (slot index = i*256 + tid) of stage `buf`; zeros come from pp_zero16.
+  auto dma_chunk = [&](int buf, auto kci) {
+    constexpr int kc = decltype(kci)::value;
+    T* xt = smem + buf * STAGE + kc * (BP + BC) * LDK;
+    T* wt = xt + BP * LDK;
+    const int c0 = it_rem * BK + pcs * EPP;
+    const bool cvalid = c0 < it_C;
+    const T* sbase = it_base;
+    const int ldc = it_ldc;
+    const int dy = it_ky * p.dh, dx = it_kx * p.dw;
+    const int64_t tapoff = (int64_t)dy * p.W + dx;
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      const int y = py0[i] + dy, x = px0[i] + dx;
+      bool ok = cvalid;
+      int64_t pix;
+      if (p.pad_mode == PP_PAD_REPLICATE) {
+        const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
+        const int xc = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
+        pix = pn[i] + (int64_t)yc * p.W + xc;
+      } else {
+        ok = ok && (y >= 0) && (y < p.H) && (x >= 0) && (x < p.W);
+        pix = prow[i] + tapoff;
+      }
+      const void* src = ok ? static_cast<const void*>(sbase + pix * ldc + c0) : static_cast<const void*>(pp_zero16);
+      glds16(src, xt + (i * 256 + wave * 64) * EPP);
+    }
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + (int64_t)it_q * BK, wt + (i * 256 + wave * 64) * EPP);
+    advance();
+  };
+  auto dma_stage = [&](int buf) { static_for<KC>([&](auto kci) { dma_chunk(buf, kci); }); };
+
   auto store_stage = [&](int buf) {
     static_for<KC>([&](auto kci) {
       constexpr int kc = decltype(kci)::value;
@@ -306,12 +345,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 #pragma unroll
       for (int i = 0; i < XPASS; ++i) {
         const int r = row0 + i * RPP;
-        if (r < BP) *reinterpret_cast<piece_t*>(xs + r * LDK + (pc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * EPP) = xreg[kc][i];
+        if (r < BP) *reinterpret_cast<piece_t*>(xs + r * LDK + pc * EPP) = xreg[kc][i];
       }
 #pragma unroll
       for (int i = 0; i < WPASS; ++i) {
         const int r = row0 + i * RPP;
-        if (r < BC) *reinterpret_cast<piece_t*>(ws + r * LDK + (pc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * EPP) = wreg[kc][i];
+        if (r < BC) *reinterpret_cast<piece_t*>(ws + r * LDK + pc * EPP) = wreg[kc][i];
       }
     });
   };
@@ -337,13 +376,20 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;  // tile rows are multiples of 16 apart: swizzle depends on frow only
 
   const int nstages = (p.nchunks + KC - 1) / KC;
-  load_stage();
-  store_stage(0);
+  if constexpr (DMA) {
+    static_assert(KC == 1, "the DMA path stages exactly one live chunk per call");
+    dma_stage(0);
+  } else {
+    load_stage();
+    store_stage(0);
+  }
   __syncthreads();
 
   for (int qs = 0; qs < nstages; ++qs) {
     const int buf = qs & 1;
-    if (qs + 1 < nstages) load_stage();
+    if (qs + 1 < nstages) {
+      if constexpr (DMA) dma_stage(buf ^ 1); else load_stage();
+    }
 
     static_for<KC>([&](auto kci) {
       constexpr int kc = decltype(kci)::value;
@@ -402,8 +448,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
       }
     });
 
-    if (qs + 1 < nstages) store_stage(buf ^ 1);
-    __syncthreads();
+    if constexpr (!DMA) {
+      if (qs + 1 < nstages) store_stage(buf ^ 1);
+    }
+    __syncthreads();  // (DMA: the barrier's release also waits for the outstanding global_load_lds, vmcnt(0))
   }
 
   // ---- epilogue -------------------------------------------------------------------------

@@ -51,10 +51,22 @@ __device__ __forceinline__ f4 mfma_16x16x4_f32(float a, float b, f4 c) {
 __device__ __forceinline__ f16v mfma_32x32x2_f32(float a, float b, f16v c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): lane l of the wave writes
+// lds_wave_base + 16*l; the base must be wave-uniform.  Completion is tracked by vmcnt (a following
+// __syncthreads() waits for it).  The source address is per lane.
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __attribute__((aligned(16))) const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #else
+inline void glds16(const void* g, void* lds_wave_base) {
+  memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * pp_emu::cur->lane, g, 16);
+}
+static const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
 inline f4 mfma_16x16x32_f16(h8 a, h8 b, f4 c) {
   struct Slot {
     h8 a, b;
