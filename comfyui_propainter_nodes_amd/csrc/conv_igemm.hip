@@ -178,6 +178,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   // DMA: tiles staged with global_load_lds (no VGPR round trip, no ds_write) when every wave-instruction of the
   // staging pass covers whole tile rows of both tiles; otherwise global -> VGPR -> LDS.
   constexpr bool DMA = (BP % RPP == 0) && (BC % RPP == 0);
+  // f16 + DMA: 3-stage ring, two chunks in flight across the (single) barrier per chunk; the MFMA phase of an f16
+  // chunk (16 x 16 cycles) is far too short to hide a global->LDS round trip with only one chunk ahead.
+  constexpr int NST = (DMA && sizeof(T) == 2) ? 3 : 2;
+  constexpr int NLOADS = XPASS + WPASS;  // global_load_lds instructions per thread per chunk
   typedef typename Frag<T>::piece piece_t;
 
   T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);  // [2 stages][KC][ X: BP rows | W: BC rows ][LDK]
@@ -385,12 +389,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   }
   __syncthreads();
 
-  for (int qs = 0; qs < nstages; ++qs) {
-    const int buf = qs & 1;
-    if (qs + 1 < nstages) {
-      if constexpr (DMA) dma_stage(buf ^ 1); else load_stage();
-    }
-
+  auto compute = [&](int buf) {
     static_for<KC>([&](auto kci) {
       constexpr int kc = decltype(kci)::value;
       const T* xt = smem + buf * STAGE + kc * (BP + BC) * LDK;
@@ -448,10 +447,32 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
       }
     });
 
-    if constexpr (!DMA) {
-      if (qs + 1 < nstages) store_stage(buf ^ 1);
+  };
+
+  if constexpr (NST == 3) {
+    // prologue issued chunk 0 (and waited for it); put chunk 1 in flight as well
+    if (nstages > 1) dma_stage(1);
+    for (int qs = 0; qs < nstages; ++qs) {
+      if (qs > 0) {
+        // chunk qs landed (this wave's part): at most the NLOADS copies of chunk qs+1 may still be in flight
+        if (qs + 1 < nstages) pp_wait_vmcnt<NLOADS>(); else pp_wait_vmcnt<0>();
+        pp_barrier();  // every wave's part of chunk qs is visible; everyone is done reading stage (qs-1)%3
+      }
+      if (qs + 2 < nstages) dma_stage((qs + 2) % 3);
+      compute(qs % 3);
     }
-    __syncthreads();  // (DMA: the barrier's release also waits for the outstanding global_load_lds, vmcnt(0))
+  } else {
+    for (int qs = 0; qs < nstages; ++qs) {
+      const int buf = qs & 1;
+      if (qs + 1 < nstages) {
+        if constexpr (DMA) dma_stage(buf ^ 1); else load_stage();
+      }
+      compute(buf);
+      if constexpr (!DMA) {
+        if (qs + 1 < nstages) store_stage(buf ^ 1);
+      }
+      __syncthreads();  // (DMA: the barrier's release also waits for the outstanding global_load_lds, vmcnt(0))
+    }
   }
 
   // ---- epilogue -------------------------------------------------------------------------
@@ -500,7 +521,9 @@ static int launch_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
   constexpr int LDK = 32;
-  const size_t smem = (size_t)2 * KC * (BC + BP) * LDK * sizeof(T);
+  constexpr int RPP = 256 / (32 / (16 / (int)sizeof(T)));
+  constexpr int NST = ((BP % RPP == 0) && (BC % RPP == 0) && sizeof(T) == 2) ? 3 : 2;  // must mirror the kernel
+  const size_t smem = (size_t)NST * KC * (BC + BP) * LDK * sizeof(T);
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem), true);
   (void)lds_ok;  // once per instantiation, not per launch

@@ -59,6 +59,16 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 __device__ __attribute__((aligned(16))) const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
+// counted wait on the vector-memory queue (global_load_lds copies are tracked by vmcnt) and a bare barrier that
+// does NOT drain that queue (unlike __syncthreads()), so copies can stay in flight across it
+template <int N>
+__device__ __forceinline__ void pp_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pp_barrier() {
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -67,6 +77,9 @@ inline void glds16(const void* g, void* lds_wave_base) {
   memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * pp_emu::cur->lane, g, 16);
 }
 static const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
+template <int N>
+inline void pp_wait_vmcnt() {}
+inline void pp_barrier() { pp_emu::barrier(); }
 inline f4 mfma_16x16x32_f16(h8 a, h8 b, f4 c) {
   struct Slot {
     h8 a, b;
