@@ -66,7 +66,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float param) {
     case PP_ACT_RELU: return v > 0.f ? v : 0.f;
     case PP_ACT_LEAKY: return v > 0.f ? v : v * param;
     case PP_ACT_SIGMOID: return sigmoidf_(v);
-    case PP_ACT_TANH: return tanhf(v);
+    case PP_ACT_TANH: return tanhf_(v);
     case PP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     default: return v;
   }
@@ -103,84 +103,139 @@ struct EpiCtx {
   const OT* pre;
 };
 
+// 4 consecutive channels of one pixel row as floats: one 8/16-byte load when `vec`, else guarded scalars
+template <typename ET>
+__device__ __forceinline__ f4 load_quad(const ET* src, bool vec, int nvalid) {
+  f4 r = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    if constexpr (sizeof(ET) == 2) {
+      const h4 t = *reinterpret_cast<const h4*>(src);
+      r = f4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    } else {
+      r = *reinterpret_cast<const f4*>(src);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nvalid) r[i] = to_f32(src[i]);
+  }
+  return r;
+}
+
+template <typename ET>
+__device__ __forceinline__ bool quad_aligned(const ET* ptr, int64_t ldc) {
+  return ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(ptr) & (4 * sizeof(ET) - 1)) == 0);
+}
+
 // bias + activation(s) + scale + fused epilogue op + channels-last store of 4 consecutive channels
 template <typename OT>
 __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, f4 accv, int64_t m, int c) {
-  float v[4] = {accv[0], accv[1], accv[2], accv[3]};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int cc = c + r;
-    float t = v[r];
-    if (e.bias && cc < p.Cout) t += e.bias[cc];
-    if (e.pre && cc < p.Cout) t += to_f32(e.pre[m * p.pre_add_ldc + cc]);
-    if (p.act_split > 0 && cc >= p.act_split) {
-      t = apply_act(t, p.act2, p.act_param);
-    } else {
-      t = apply_act(t, p.act, p.act_param);
-      if (p.out_scale != 0.f) t *= p.out_scale;
-    }
-    v[r] = t;
+  const int nvalid = p.Cout - c;  // >= 1 (caller checks c < Cout)
+  const bool full = nvalid >= 4;
+  f4 v = accv;
+  if (e.bias) {
+    const f4 b = load_quad(e.bias + c, full && ((c & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0), nvalid);
+    v += b;
   }
-  if (p.epi != PP_EPI_NONE) {
+  if (e.pre) {
+    const OT* src = e.pre + m * p.pre_add_ldc + c;
+    v += load_quad(src, full && quad_aligned(src, p.pre_add_ldc), nvalid);
+  }
+  if (p.act_split > 0 && c + 3 >= p.act_split && c < p.act_split) {
+    // quad straddles the act/act2 boundary (never happens for the shipped nets: split % 4 == 0)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int cc = c + r;
-      if (cc < p.Cout) {
-        const float a1 = to_f32(e.aux1[m * p.aux1_ldc + cc]);
-        if (p.epi == PP_EPI_MUL_AUX1) {
-          v[r] *= a1;
-        } else if (p.epi == PP_EPI_ADD_AUX1) {
-          v[r] += a1;
-        } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
-          const float s = v[r] + a1;
-          v[r] = s > 0.f ? s : 0.f;
-        } else if (p.epi == PP_EPI_GRU) {
-          const float h = to_f32(e.aux2[m * p.aux2_ldc + cc]);
-          v[r] = (1.f - a1) * h + a1 * v[r];
-        }
+      if (c + r >= p.act_split) {
+        v[r] = apply_act(v[r], p.act2, p.act_param);
+      } else {
+        v[r] = apply_act(v[r], p.act, p.act_param);
+        if (p.out_scale != 0.f) v[r] *= p.out_scale;
       }
+    }
+  } else if (p.act_split > 0 && c >= p.act_split) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2, p.act_param);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.act_param);
+    if (p.out_scale != 0.f) v *= p.out_scale;
+  }
+  if (p.epi != PP_EPI_NONE) {
+    const OT* s1 = e.aux1 + m * p.aux1_ldc + c;
+    const f4 a1 = load_quad(s1, full && quad_aligned(s1, p.aux1_ldc), nvalid);
+    if (p.epi == PP_EPI_MUL_AUX1) {
+      v *= a1;
+    } else if (p.epi == PP_EPI_ADD_AUX1) {
+      v += a1;
+    } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = v[r] + a1[r];
+        v[r] = s > 0.f ? s : 0.f;
+      }
+    } else if (p.epi == PP_EPI_GRU) {
+      const OT* s2 = e.aux2 + m * p.aux2_ldc + c;
+      const f4 h = load_quad(s2, full && quad_aligned(s2, p.aux2_ldc), nvalid);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (1.f - a1[r]) * h[r] + a1[r] * v[r];
     }
   }
   OT* dst = e.out + m * p.out_ldc + c;
-  const bool vec_ok = (c + 3 < p.Cout) && ((p.out_ldc & 3) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(OT) - 1)) == 0);
-  if (vec_ok) {
+  if (full && quad_aligned(dst, p.out_ldc)) {
     if constexpr (sizeof(OT) == 2) {
       h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
       *reinterpret_cast<h4*>(dst) = o;
     } else {
-      f4 o = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f4*>(dst) = o;
+      *reinterpret_cast<f4*>(dst) = v;
     }
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (c + r < p.Cout) dst[r] = from_f32<OT>(v[r]);
+      if (r < nvalid) dst[r] = from_f32<OT>(v[r]);
   }
 }
 
+// Staging geometry shared by the kernel and its launcher.
+template <typename T, int BC, int BP>
+struct TileGeom {
+  static constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
+  // K chunk staged per pipeline step: 32 channels of one (tap, segment); f32 tiles whose rows fill whole
+  // 64-row DMA passes use 16-channel half chunks so that a 3-stage ring still fits 3 work-groups per CU
+  static constexpr int BK = (sizeof(T) == 4 && BP % 64 == 0 && BC % 64 == 0) ? 16 : 32;
+  static constexpr int PPR = BK / EPP;   // 16-byte pieces per tile row
+  static constexpr int RPP = 256 / PPR;  // tile rows filled per 256-thread pass
+  // DMA: tiles staged with global_load_lds (no VGPR round trip, no ds_write) when every wave-instruction of the
+  // staging pass covers whole tile rows of both tiles; otherwise global -> VGPR -> LDS.
+  static constexpr bool DMA = (BP % RPP == 0) && (BC % RPP == 0);
+  // 3-stage ring (two chunks in flight across the single barrier per chunk) when one stage is <= 16 KiB
+  static constexpr int NST = (DMA && (sizeof(T) == 2 || BK == 16)) ? 3 : 2;
+};
+
 template <typename T, typename OT, int WC, int WP, int TC, int TP, bool M32, int KC>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
-  constexpr int BK = 32;                    // one K chunk = 32 channels of one (tap, segment)
-  constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
-  constexpr int PPR = BK / EPP;             // pieces per tile row (4 f16, 8 f32)
+  typedef TileGeom<T, WC * TC * 16, WP * TP * 16> G;
+  constexpr int BK = G::BK;
+  constexpr int CM = 32 / BK;    // pipeline steps per 32-channel chunk of the packed weights
+  constexpr int EPP = G::EPP;
+  constexpr int PPR = G::PPR;    // pieces per tile row (4 f16, 8 / 4 f32)
   constexpr int LDK = BK;                   // LDS row pitch in elements (no padding: XOR-swizzled pieces)
   // 16-byte piece p of tile row r is stored at piece p ^ swz(r): conflict-free for the ds_read_b128
   // lane groups AND the ds_write_b128 groups of gfx950 (f16: 4 pieces/row, f32: 8 pieces/row)
   constexpr int SWZ_MASK = PPR - 1;
-  constexpr int SWZ_SHIFT = 1;  // swz(r) = (r >> 1) & (PPR - 1): also conflict-free for the 32-row M32 read pattern
+  // swz(r) = (r >> SWZ_SHIFT) & (PPR - 1).  The 16-lane service groups of ds_read_b128 must hit 16 distinct
+  // 16-byte bank slots: shift 1 does that for 64-byte rows read 16 rows x 4 k-groups (f16, 16x16 f32) and for
+  // 128-byte rows read 32 rows x 2 k-halves (M32, BK 32); 64-byte rows read 32 x 2 (M32, BK 16) need shift 2.
+  constexpr int SWZ_SHIFT = (M32 && PPR == 4) ? 2 : 1;
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
-  constexpr int RPP = 256 / PPR;  // rows filled per pass
+  constexpr int RPP = G::RPP;  // rows filled per pass
   constexpr int XPASS = (BP + RPP - 1) / RPP;
   constexpr int WPASS = (BC + RPP - 1) / RPP;
   constexpr int STAGE = KC * (BP + BC) * LDK;  // elements per pipeline stage (KC chunks per barrier)
-  // DMA: tiles staged with global_load_lds (no VGPR round trip, no ds_write) when every wave-instruction of the
-  // staging pass covers whole tile rows of both tiles; otherwise global -> VGPR -> LDS.
-  constexpr bool DMA = (BP % RPP == 0) && (BC % RPP == 0);
-  // f16 + DMA: 3-stage ring, two chunks in flight across the (single) barrier per chunk; the MFMA phase of an f16
-  // chunk (16 x 16 cycles) is far too short to hide a global->LDS round trip with only one chunk ahead.
-  constexpr int NST = (DMA && sizeof(T) == 2) ? 3 : 2;
+  constexpr bool DMA = G::DMA;
+  // NST == 3: two chunks in flight across the (single) barrier per chunk; the MFMA phase of one chunk is too
+  // short to hide a global->LDS round trip with only one chunk ahead.
+  constexpr int NST = G::NST;
   constexpr int NLOADS = XPASS + WPASS;  // global_load_lds instructions per thread per chunk
   typedef typename Frag<T>::piece piece_t;
 
@@ -234,7 +289,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   // indices only, so the kernel-argument arrays stay in SGPRs instead of being copied to scratch.
   int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
   const T* it_base = reinterpret_cast<const T*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
-  int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0];
+  int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0] * CM;
   auto select_segment = [&](int seg) {
 #pragma unroll
     for (int s = 0; s < PP_MAX_SEG; ++s) {
@@ -242,7 +297,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         it_base = reinterpret_cast<const T*>(p.in_ptr[s]) + (int64_t)z * p.in_zoff[s];
         it_C = p.in_C[s];
         it_ldc = p.in_ldc[s];
-        it_chunks = p.seg_chunks[s];
+        it_chunks = p.seg_chunks[s] * CM;
       }
     }
   };
@@ -266,7 +321,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   // are zeroed by a select; tile rows past M / Cout read a clamped row, their results are never stored.
   auto load_chunk = [&](auto kci) {
     constexpr int kc = decltype(kci)::value;
-    const bool live = (KC == 1) || (it_q < p.nchunks);
+    const bool live = (KC == 1) || (it_q < p.nchunks * CM);
     const int c0 = it_rem * BK + pcs * EPP;
     const bool cvalid = live && (c0 < it_C);
     const T* sbase = it_base;
@@ -379,7 +434,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   const int fgrp = lane >> 4;
   const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;  // tile rows are multiples of 16 apart: swizzle depends on frow only
 
-  const int nstages = (p.nchunks + KC - 1) / KC;
+  const int nstages = (p.nchunks * CM + KC - 1) / KC;
   if constexpr (DMA) {
     static_assert(KC == 1, "the DMA path stages exactly one live chunk per call");
     dma_stage(0);
@@ -410,14 +465,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         const T* xs32 = xt + (wp * TP * 16 + r32) * LDK;
         const T* ws32 = wt + (wc * TC * 16 + r32) * LDK;
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {  // 8 k per sub-chunk: lane half kh32 supplies k = 4*kh32 + j at step j
+        for (int sub = 0; sub < BK / 8; ++sub) {  // 8 k per sub-chunk: lane half kh32 supplies k = 4*kh32 + j at step j
           f4 af[TC2], bf[TP2];
 #pragma unroll
           for (int a = 0; a < TC2; ++a)
-            af[a] = *reinterpret_cast<const f4*>(ws32 + a * 32 * LDK + ((sub * 2 + kh32) ^ ((r32 >> 1) & 7)) * 4);
+            af[a] = *reinterpret_cast<const f4*>(ws32 + a * 32 * LDK + ((sub * 2 + kh32) ^ ((r32 >> SWZ_SHIFT) & SWZ_MASK)) * 4);
 #pragma unroll
           for (int b = 0; b < TP2; ++b)
-            bf[b] = *reinterpret_cast<const f4*>(xs32 + b * 32 * LDK + ((sub * 2 + kh32) ^ ((r32 >> 1) & 7)) * 4);
+            bf[b] = *reinterpret_cast<const f4*>(xs32 + b * 32 * LDK + ((sub * 2 + kh32) ^ ((r32 >> SWZ_SHIFT) & SWZ_MASK)) * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -429,7 +484,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         const T* xs = xt + (wp * TP * 16 + frow) * LDK;
         const T* ws = wt + (wc * TC * 16 + frow) * LDK;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < BK / 16; ++sub) {
           f4 af[TC], bf[TP];
 #pragma unroll
           for (int a = 0; a < TC; ++a)
@@ -520,10 +575,8 @@ static int launch_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int KC = 1;
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
-  constexpr int LDK = 32;
-  constexpr int RPP = 256 / (32 / (16 / (int)sizeof(T)));
-  constexpr int NST = ((BP % RPP == 0) && (BC % RPP == 0) && sizeof(T) == 2) ? 3 : 2;  // must mirror the kernel
-  const size_t smem = (size_t)NST * KC * (BC + BP) * LDK * sizeof(T);
+  typedef TileGeom<T, BC, BP> G;
+  const size_t smem = (size_t)G::NST * KC * (BC + BP) * G::BK * sizeof(T);
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem), true);
   (void)lds_ok;  // once per instantiation, not per launch

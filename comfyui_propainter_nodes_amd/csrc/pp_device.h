@@ -184,7 +184,21 @@ __device__ __forceinline__ half_t from_f32<half_t>(float v) {
   return (half_t)v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence
+__device__ __forceinline__ float fast_rcp(float x) {
+#ifdef PP_EMU
+  return 1.f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.f + __expf(-x)); }
+// tanh(x) = sign(x) (1 - e^{-2|x|}) / (1 + e^{-2|x|}); absolute error < 1e-7
+__device__ __forceinline__ float tanhf_(float x) {
+  const float t = __expf(-2.f * fabsf(x));
+  const float r = (1.f - t) * fast_rcp(1.f + t);
+  return copysignf(r, x);
+}
 
 __device__ __forceinline__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
