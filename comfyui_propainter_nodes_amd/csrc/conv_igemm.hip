@@ -201,12 +201,18 @@ struct TileGeom {
   static constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
   // K chunk staged per pipeline step: 32 channels of one (tap, segment); f32 tiles whose rows fill whole
   // 64-row DMA passes use 16-channel half chunks so that a 3-stage ring still fits 3 work-groups per CU
-  static constexpr int BK = (sizeof(T) == 4 && BP % 64 == 0 && BC % 64 == 0) ? 16 : 32;
+  // (the weight tile may be padded by up to a third to whole passes: 96 -> 128 rows)
+  // (f32 only: measured on MI355X, the padded-DMA 96-wide f16 tile is slower than its register-staged form)
+  static constexpr bool pad_ok(int rows, int rpp) {
+    return sizeof(T) == 4 ? ((rows + rpp - 1) / rpp * rpp - rows) * 3 <= rows : rows % rpp == 0;
+  }
+  static constexpr int BK = (sizeof(T) == 4 && BP % 64 == 0 && pad_ok(BC, 64)) ? 16 : 32;
   static constexpr int PPR = BK / EPP;   // 16-byte pieces per tile row
   static constexpr int RPP = 256 / PPR;  // tile rows filled per 256-thread pass
   // DMA: tiles staged with global_load_lds (no VGPR round trip, no ds_write) when every wave-instruction of the
   // staging pass covers whole tile rows of both tiles; otherwise global -> VGPR -> LDS.
-  static constexpr bool DMA = (BP % RPP == 0) && (BC % RPP == 0);
+  static constexpr bool DMA = (BP % RPP == 0) && pad_ok(BC, RPP);
+  static constexpr int BCP = DMA ? (BC + RPP - 1) / RPP * RPP : BC;  // weight-tile rows allocated in LDS
   // 3-stage ring (two chunks in flight across the single barrier per chunk) when one stage is <= 16 KiB
   static constexpr int NST = (DMA && (sizeof(T) == 2 || BK == 16)) ? 3 : 2;
 };
@@ -231,7 +237,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   constexpr int RPP = G::RPP;  // rows filled per pass
   constexpr int XPASS = (BP + RPP - 1) / RPP;
   constexpr int WPASS = (BC + RPP - 1) / RPP;
-  constexpr int STAGE = KC * (BP + BC) * LDK;  // elements per pipeline stage (KC chunks per barrier)
+  constexpr int BCP = G::BCP;
+  constexpr int STAGE = KC * (BP + BCP) * LDK;  // elements per pipeline stage (KC chunks per barrier)
   constexpr bool DMA = G::DMA;
   // NST == 3: two chunks in flight across the (single) barrier per chunk; the MFMA phase of one chunk is too
   // short to hide a global->LDS round trip with only one chunk ahead.
@@ -366,7 +373,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   // straight into the lane-linear LDS image (slot index = i*256 + tid) of stage `buf`; zeros come from pp_zero16.
   auto dma_chunk = [&](int buf, auto kci) {
     constexpr int kc = decltype(kci)::value;
-    T* xt = smem + buf * STAGE + kc * (BP + BC) * LDK;
+    T* xt = smem + buf * STAGE + kc * (BP + BCP) * LDK;
     T* wt = xt + BP * LDK;
     const int c0 = it_rem * BK + pcs * EPP;
     const bool cvalid = c0 < it_C;
@@ -399,7 +406,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   auto store_stage = [&](int buf) {
     static_for<KC>([&](auto kci) {
       constexpr int kc = decltype(kci)::value;
-      T* xs = smem + buf * STAGE + kc * (BP + BC) * LDK;
+      T* xs = smem + buf * STAGE + kc * (BP + BCP) * LDK;
       T* ws = xs + BP * LDK;
 #pragma unroll
       for (int i = 0; i < XPASS; ++i) {
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   auto compute = [&](int buf) {
     static_for<KC>([&](auto kci) {
       constexpr int kc = decltype(kci)::value;
-      const T* xt = smem + buf * STAGE + kc * (BP + BC) * LDK;
+      const T* xt = smem + buf * STAGE + kc * (BP + BCP) * LDK;
       const T* wt = xt + BP * LDK;
       if constexpr (sizeof(T) == 2) {
         const T* xs = xt + (wp * TP * 16 + frow) * LDK;
@@ -566,6 +573,259 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// f32 convolution on the f16 matrix pipe ("split" mode, dtype PP_F32X2).
+//
+// Every f32 operand value v is represented by two f16 terms  v ~= h + l / 2048,  h = f16(v),
+// l = f16((v - h) * 2048)  (22 significand bits; the 2048 keeps l out of the f16 denormal range).  Then
+//     sum_k w x  ~=  sum_k wh xh  +  ( sum_k wh xl + sum_k wl xh ) / 2048        (the wl xl term is < 2^-22)
+// i.e. three v_mfma_f32_16x16x32_f16 (16x the f32 MFMA rate each) into two fp32 accumulator sets instead of
+// sixteen v_mfma_f32_32x32x2_f32 steps: the same result to fp32 rounding noise, for |v| < 32752.
+//
+// LDS tile row = one 32-channel chunk = 128 bytes = 8 16-byte slots: slots 0-3 the h terms (k 0-31), 4-7 the
+// l terms, slot s stored at s ^ swz(row).  Weights are split on the host (same byte size and chunk
+// order as the f32 packing) and copied by global_load_lds; pixels are loaded as f32 (8 channels per thread), split
+// in registers and written with one ds_write_b128 per plane.  Two stages, one barrier per chunk.
+template <typename OT, int WC, int WP, int TC, int TP>
+__global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
+  constexpr int BC = WC * TC * 16;
+  constexpr int BP = WP * TP * 16;
+  constexpr int BCP = (BC + 31) / 32 * 32;  // weight rows staged (rows past BC are never read)
+  constexpr int ROWB = 128;                 // bytes per tile row
+  constexpr int XPASS = (BP + 63) / 64;     // pixel passes: 4 threads per row (8 channels each), 64 rows per pass
+  constexpr int WPASS = BCP / 32;           // weight passes: 8 threads per row (16 bytes each), 32 rows per pass
+  constexpr int STAGE = (BP + BCP) * ROWB;
+  constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
+
+  unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wc = wave / WP;
+  const int wp = wave % WP;
+  const int z = (int)blockIdx.z;
+  const int64_t p_base = (int64_t)blockIdx.x * BP;
+  const int c_base = (int)blockIdx.y * BC;
+
+  // slot swizzle of tile row r (depends on r mod 16 only): swz(r) = ((r >> 1) & 7) ^ ((r & 1) << 2).
+  //  - fragment reads (16 rows x 4 k-groups per plane): every 16-lane service group of ds_read_b128 hits 16
+  //    distinct 16-byte slots of the 256-byte bank row;
+  //  - pixel writes (ds_write_b128, 8-lane groups = 2 rows x 4 slots of one plane): the odd row's plane lives in
+  //    the other half of the 128-byte row, so the 8 lanes cover 8 distinct slots.
+  auto swz = [](int r) { return ((r >> 1) & 7) ^ ((r & 1) << 2); };
+
+  // weights: lane-linear DMA image, LDS slot pc of row wrow0 holds source piece pc ^ swz
+  const int pc = tid & 7;
+  const int wrow0 = tid >> 3;
+  const int pcs = pc ^ swz(wrow0);
+  // pixels: thread = (row xrow0 + 64 i, channel octet xj): h octet -> slot xj ^ swz, l octet -> slot (xj + 4) ^ swz
+  const int xj = tid & 3;
+  const int xrow0 = tid >> 2;
+  const int xoff_h = (xj ^ swz(xrow0)) << 4;
+  const int xoff_l = ((xj + 4) ^ swz(xrow0)) << 4;
+
+  // per pass: pixel index of tap (0,0) and its (y, x), packed to 16 bits each
+  int64_t prow[XPASS];
+  int pyx[XPASS];
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) {
+    const int r = xrow0 + i * 64;
+    const int64_t m = p_base + r;
+    const int64_t mm = (r < BP && m < p.M) ? m : p.M - 1;  // rows past M: clamped, results never stored
+    const int wo = (int)(mm % p.Wo);
+    const int64_t t = mm / p.Wo;
+    const int ho = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    const int y0 = ho * p.sh - p.ph, x0 = wo * p.sw - p.pw;
+    prow[i] = (int64_t)n * p.H * p.W + (int64_t)y0 * p.W + x0;
+    pyx[i] = (int)(((unsigned)y0 << 16) | ((unsigned)x0 & 0xffffu));
+  }
+  const float* wbase = reinterpret_cast<const float*>(p.weight) + (int64_t)z * p.w_zoff;
+  const float* wrow[WPASS];
+#pragma unroll
+  for (int i = 0; i < WPASS; ++i) {
+    const int co = c_base + wrow0 + i * 32;
+    wrow[i] = wbase + (int64_t)(co < p.Cout ? co : p.Cout - 1) * p.Kp + pcs * 4;
+  }
+
+  f4 xreg[XPASS][2];
+
+  int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
+  const float* it_base = reinterpret_cast<const float*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
+  int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0];
+  auto select_segment = [&](int seg) {
+#pragma unroll
+    for (int s = 0; s < PP_MAX_SEG; ++s) {
+      if (seg == s) {
+        it_base = reinterpret_cast<const float*>(p.in_ptr[s]) + (int64_t)z * p.in_zoff[s];
+        it_C = p.in_C[s];
+        it_ldc = p.in_ldc[s];
+        it_chunks = p.seg_chunks[s];
+      }
+    }
+  };
+  auto advance = [&]() {
+    ++it_q;
+    if (++it_rem == it_chunks) {
+      it_rem = 0;
+      if (p.nseg > 1 || p.kh * p.kw > 1) {
+        if (++it_seg == p.nseg) {
+          it_seg = 0;
+          if (++it_kx == p.kw) {
+            it_kx = 0;
+            ++it_ky;
+          }
+        }
+        if (p.nseg > 1) select_segment(it_seg);
+      }
+    }
+  };
+
+  // next chunk of the K iterator: weights -> LDS stage `buf` (DMA), pixels -> registers (unconditional loads;
+  // out-of-image taps and padded channels read a safe address and are zeroed by a select)
+  auto fetch = [&](int buf) {
+    unsigned char* wt = smem + buf * STAGE + BP * ROWB;
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + (int64_t)it_q * 32, wt + (i * 256 + wave * 64) * 16);
+    const int c0 = it_rem * 32 + xj * 8;
+    const int dy = it_ky * p.dh, dx = it_kx * p.dw;
+    const int64_t tapoff = (int64_t)dy * p.W + dx;
+    const float* cbase = it_base + c0;
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      const int y = (pyx[i] >> 16) + dy, x = (int)(short)(pyx[i] & 0xffff) + dx;
+      bool ok = true;
+      int64_t pix;
+      if (p.pad_mode == PP_PAD_REPLICATE) {
+        const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
+        const int xc = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
+        pix = prow[i] + (int64_t)(yc - (pyx[i] >> 16)) * p.W + (xc - (int)(short)(pyx[i] & 0xffff));
+      } else {
+        ok = ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
+        pix = prow[i] + tapoff;
+      }
+      // segment channel counts are multiples of 4: each half octet is either fully valid or padding
+      const bool ok0 = ok && (c0 < it_C), ok1 = ok && (c0 + 4 < it_C);
+      const float* src = ok0 ? cbase + pix * it_ldc : it_base;
+      f4 v0 = *reinterpret_cast<const f4*>(src);
+      f4 v1 = *reinterpret_cast<const f4*>(src + (ok1 ? 4 : 0));
+      if (!ok0) v0 = f4{0.f, 0.f, 0.f, 0.f};
+      if (!ok1) v1 = f4{0.f, 0.f, 0.f, 0.f};
+      xreg[i][0] = v0;
+      xreg[i][1] = v1;
+    }
+    advance();
+  };
+  // split the fetched pixels (h: round toward zero, saturating; l: the exact remainder * 2048, round to nearest)
+  // and write one 16-byte octet per plane
+  auto store_x = [&](int buf) {
+    unsigned char* xs = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      if (BP % 64 != 0 && xrow0 + i * 64 >= BP) continue;
+      h8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float c0 = xreg[i][e >> 2][e & 3], c1 = xreg[i][e >> 2][(e & 3) + 1];
+        const h2 hh = cvt_pkrtz_f16(c0, c1);
+        h[e] = hh[0];
+        h[e + 1] = hh[1];
+        l[e] = (half_t)((c0 - (float)hh[0]) * LSCALE);
+        l[e + 1] = (half_t)((c1 - (float)hh[1]) * LSCALE);
+      }
+      unsigned char* rowp = xs + (xrow0 + i * 64) * ROWB;
+      *reinterpret_cast<h8*>(rowp + xoff_h) = h;
+      *reinterpret_cast<h8*>(rowp + xoff_l) = l;
+    }
+  };
+
+  f4 acc[TC][TP], accx[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+      accx[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  const int frow = lane & 15;
+  const int fgrp = lane >> 4;
+  const int roff_h = (fgrp ^ swz(frow)) << 4;
+  const int roff_l = ((fgrp + 4) ^ swz(frow)) << 4;
+
+  auto compute = [&](int buf) {
+    const unsigned char* xs = smem + buf * STAGE + (wp * TP * 16 + frow) * ROWB;
+    const unsigned char* ws = smem + buf * STAGE + BP * ROWB + (wc * TC * 16 + frow) * ROWB;
+    h8 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a) {
+      ah[a] = *reinterpret_cast<const h8*>(ws + a * 16 * ROWB + roff_h);
+      al[a] = *reinterpret_cast<const h8*>(ws + a * 16 * ROWB + roff_l);
+    }
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      bh[b] = *reinterpret_cast<const h8*>(xs + b * 16 * ROWB + roff_h);
+      bl[b] = *reinterpret_cast<const h8*>(xs + b * 16 * ROWB + roff_l);
+    }
+    // three sweeps over the tile grid: two MFMAs on one accumulator are always TC*TP instructions apart
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bh[b], acc[a][b]);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(ah[a], bl[b], accx[a][b]);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(al[a], bh[b], accx[a][b]);
+  };
+
+  const int nstages = p.nchunks;
+  fetch(0);
+  store_x(0);
+  __syncthreads();
+  for (int qs = 0; qs < nstages; ++qs) {
+    const int buf = qs & 1;
+    if (qs + 1 < nstages) fetch(buf ^ 1);
+    compute(buf);
+    if (qs + 1 < nstages) store_x(buf ^ 1);
+    __syncthreads();  // also drains the weight copies (vmcnt(0))
+  }
+
+  EpiCtx<OT> e;
+  e.bias = p.bias ? p.bias + (int64_t)z * p.bias_zoff : nullptr;
+  e.out = reinterpret_cast<OT*>(p.out) + (int64_t)z * p.out_zoff;
+  e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
+  e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
+  e.pre = reinterpret_cast<const OT*>(p.pre_add);
+  static_for<TP>([&](auto bi) {
+    constexpr int b = decltype(bi)::value;
+    const int64_t m = p_base + wp * TP * 16 + b * 16 + frow;
+    static_for<TC>([&](auto ai) {
+      constexpr int a = decltype(ai)::value;
+      const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
+      const f4 v = acc[a][b] + accx[a][b] * LINV;
+      if (m < p.M && c < p.Cout) store_quad<OT>(p, e, v, m, c);
+    });
+  });
+}
+
+template <typename OT, int WC, int WP, int TC, int TP>
+static int launch_split_cfg(void* stream, const ConvK& k, int Z) {
+  constexpr int BC = WC * TC * 16;
+  constexpr int BP = WP * TP * 16;
+  constexpr int BCP = (BC + 31) / 32 * 32;
+  const size_t smem = (size_t)2 * (BP + BCP) * 128;
+  dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
+  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_split_kernel<OT, WC, WP, TC, TP>), smem), true);
+  (void)lds_ok;
+  PP_LAUNCH((conv_split_kernel<OT, WC, WP, TC, TP>), grid, dim3(256), smem, stream, k);
+  return pp_check_launch("pp_conv2d");
+}
+
 template <typename T, typename OT, int WC, int WP, int TC, int TP>
 static int launch_cfg(void* stream, const ConvK& k, int Z) {
   // f32: 32x32x2 MFMA tiles whenever the per-wave tile is a multiple of 32x32
@@ -576,7 +836,7 @@ static int launch_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
   typedef TileGeom<T, BC, BP> G;
-  const size_t smem = (size_t)G::NST * KC * (BC + BP) * G::BK * sizeof(T);
+  const size_t smem = (size_t)G::NST * KC * (G::BCP + BP) * G::BK * sizeof(T);
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem), true);
   (void)lds_ok;  // once per instantiation, not per launch
@@ -584,7 +844,21 @@ static int launch_cfg(void* stream, const ConvK& k, int Z) {
   return pp_check_launch("pp_conv2d");
 }
 
+// Launchers of one (T, OT) kernel family for a wave arrangement WC x WP with TC x TP MFMA tiles per wave.
 template <typename T, typename OT>
+struct IgemmFamily {
+  template <int WC, int WP, int TC, int TP>
+  static int run(void* stream, const ConvK& k, int Z) { return launch_cfg<T, OT, WC, WP, TC, TP>(stream, k, Z); }
+  static constexpr bool m32_wide96 = sizeof(T) == 4;
+};
+template <typename OT>
+struct SplitFamily {
+  template <int WC, int WP, int TC, int TP>
+  static int run(void* stream, const ConvK& k, int Z) { return launch_split_cfg<OT, WC, WP, TC, TP>(stream, k, Z); }
+  static constexpr bool m32_wide96 = false;
+};
+
+template <typename F>
 static int launch_by_cout(void* stream, const ConvK& k, int Z) {
   // Small problems (the per-step convolutions of the two recurrences: M = 2*45*80 or 90*160 pixels) would
   // fill only a fraction of the 256 CUs with 128-pixel tiles: switch to 32-pixel tiles (4x the work-groups).
@@ -595,19 +869,23 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
   }();
   const bool small = forced == 2 || (forced == 0 && blocks128 < 224);
   if (k.Cout > 64) {
-    if (small) return launch_cfg<T, OT, 4, 1, 2, 2>(stream, k, Z);                     // 128 x  32
+    if (small) return F::template run<4, 1, 2, 2>(stream, k, Z);                     // 128 x  32
     // 96-wide tiles when they waste clearly fewer output channels than 128-wide ones (Cout 192, 576, ...)
     const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
     const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
-    if (waste96 + 32 <= waste128) return launch_cfg<T, OT, 2, 2, 3, 4>(stream, k, Z);  //  96 x 128
-    return launch_cfg<T, OT, 2, 2, 4, 4>(stream, k, Z);                                // 128 x 128
+    if (waste96 + 32 <= waste128) {                                                  //  96 x 128
+      // f32 MFMA: one wave column of 96 x 32 so that the wave tile is made of 32x32 MFMA blocks
+      if constexpr (F::m32_wide96) return F::template run<1, 4, 6, 2>(stream, k, Z);
+      else return F::template run<2, 2, 3, 4>(stream, k, Z);
+    }
+    return F::template run<2, 2, 4, 4>(stream, k, Z);                                // 128 x 128
   }
   if (k.Cout > 32) {
-    if (small) return launch_cfg<T, OT, 2, 2, 2, 1>(stream, k, Z);                     //  64 x  32
-    return launch_cfg<T, OT, 1, 4, 4, 2>(stream, k, Z);                                //  64 x 128
+    if (small) return F::template run<2, 2, 2, 1>(stream, k, Z);                     //  64 x  32
+    return F::template run<1, 4, 4, 2>(stream, k, Z);                                //  64 x 128
   }
-  if (k.Cout > 16) return launch_cfg<T, OT, 1, 4, 2, 2>(stream, k, Z);                 //  32 x 128
-  return launch_cfg<T, OT, 1, 4, 1, 4>(stream, k, Z);                                  //  16 x 256
+  if (k.Cout > 16) return F::template run<1, 4, 2, 2>(stream, k, Z);                 //  32 x 128
+  return F::template run<1, 4, 1, 4>(stream, k, Z);                                  //  16 x 256
 }
 
 }  // namespace pp
@@ -616,7 +894,8 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   using namespace pp;
   if (!p) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: null params");
   if (p->nseg < 1 || p->nseg > PP_MAX_SEG) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: nseg out of range");
-  if (p->dtype != PP_F32 && p->dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: dtype");
+  if (p->dtype != PP_F32 && p->dtype != PP_F16 && p->dtype != PP_F32X2)
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: dtype");
   if (p->out_dtype != PP_F32 && p->out_dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: out_dtype");
   if (!p->weight || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: null weight/out");
   if (p->Z < 1 || p->Z > 65535) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: Z out of range");
@@ -667,9 +946,13 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   if (p->pre_add && p->Z != 1) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: pre_add with Z > 1");
   const int Z = (int)p->Z;
   if (p->dtype == PP_F16) {
-    if (p->out_dtype == PP_F16) return launch_by_cout<half_t, half_t>(stream, k, Z);
-    return launch_by_cout<half_t, float>(stream, k, Z);
+    if (p->out_dtype == PP_F16) return launch_by_cout<IgemmFamily<half_t, half_t>>(stream, k, Z);
+    return launch_by_cout<IgemmFamily<half_t, float>>(stream, k, Z);
   }
-  if (p->out_dtype == PP_F16) return launch_by_cout<float, half_t>(stream, k, Z);
-  return launch_by_cout<float, float>(stream, k, Z);
+  if (p->dtype == PP_F32X2) {
+    if (p->out_dtype != PP_F32) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: PP_F32X2 writes f32 only");
+    return launch_by_cout<SplitFamily<float>>(stream, k, Z);
+  }
+  if (p->out_dtype == PP_F16) return launch_by_cout<IgemmFamily<float, half_t>>(stream, k, Z);
+  return launch_by_cout<IgemmFamily<float, float>>(stream, k, Z);
 }

@@ -184,6 +184,29 @@ __device__ __forceinline__ half_t from_f32<half_t>(float v) {
   return (half_t)v;
 }
 
+// two floats -> two f16, round toward zero (saturates at +-65504 instead of overflowing to infinity)
+__device__ __forceinline__ h2 cvt_pkrtz_f16(float a, float b) {
+#ifdef PP_EMU
+  auto rtz = [](float x) -> half_t {
+    if (x != x) return (half_t)x;
+    if (x > 65504.f) return (half_t)65504.f;
+    if (x < -65504.f) return (half_t)-65504.f;
+    half_t h = (half_t)x;  // round to nearest even
+    const float hf = (float)h;
+    if ((hf > x && x > 0.f) || (hf < x && x < 0.f)) {  // rounded away from zero: step one ulp back
+      unsigned short bits;
+      memcpy(&bits, &h, 2);
+      bits -= 1;
+      memcpy(&h, &bits, 2);
+    }
+    return h;
+  };
+  return h2{rtz(a), rtz(b)};
+#else
+  return __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
+#endif
+}
+
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence
 __device__ __forceinline__ float fast_rcp(float x) {
 #ifdef PP_EMU

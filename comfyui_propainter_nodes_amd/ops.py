@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes
 from dataclasses import dataclass
 
+import os
+
 import torch
 
 from . import lib as _lib
@@ -141,6 +143,21 @@ def pack_conv_weight(w: torch.Tensor, seg_channels: list[int], dtype: torch.dtyp
     return out.reshape(cout, kh * kw * kp).to(dtype).contiguous()
 
 
+def f32_split_enabled() -> bool:
+    """PP_F32_GEMM=exact keeps f32 convolutions on the f32 MFMA instructions; default: PP_F32X2 (split) mode."""
+    return os.environ.get("PP_F32_GEMM", "split").lower() != "exact"
+
+
+def split_pack_weight(packed: torch.Tensor) -> torch.Tensor:
+    """PP_F32X2 weight format: every 32-channel chunk [w0..w31] of an f32 packing becomes 32 f16 `h = f16(w)`
+    followed by 32 f16 `l = f16((w - h) * 2048)`; returned as an f32-typed bit container of the same shape."""
+    cout, kp = packed.shape
+    w = packed.float().reshape(cout, kp // 32, 32)
+    h = w.clamp(-65504.0, 65504.0).half()
+    l = ((w - h.float()) * 2048.0).half()
+    return torch.cat([h, l], dim=2).contiguous().view(torch.float32).reshape(cout, kp)
+
+
 @dataclass
 class ConvSpec:
     """Geometry + packed parameters of one convolution / linear layer."""
@@ -160,6 +177,7 @@ class ConvSpec:
     groups: int = 1
     pad_mode: str = "zeros"
     cin_valid: int = 0            # real (unpadded) input channels per group, for FLOP accounting
+    split: bool = False           # f32 tensors on the f16 matrix pipe (PP_F32X2 weight packing)
 
     def to(self, device) -> "ConvSpec":
         self.weight = self.weight.to(device)
@@ -174,7 +192,8 @@ class ConvSpec:
 
 
 def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, *, stride=1, padding=0,
-                   dilation=1, groups=1, seg_channels=None, seg_valid=None, pad_mode="zeros") -> ConvSpec:
+                   dilation=1, groups=1, seg_channels=None, seg_valid=None, pad_mode="zeros",
+                   split: bool = False) -> ConvSpec:
     def pair(v):
         return (v, v) if isinstance(v, int) else tuple(v)
 
@@ -184,9 +203,13 @@ def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, 
     dh, dw = pair(dilation)
     seg_channels = seg_channels or [cin_g]
     packed = pack_conv_weight(w, seg_channels, dtype, seg_valid)
+    if split:
+        if dtype != torch.float32:
+            raise TypeError("split packing applies to f32 convolutions only")
+        packed = split_pack_weight(packed)
     bias = b.detach().float().contiguous() if b is not None else None
     return ConvSpec(packed, bias, list(seg_channels), cout // groups, kh, kw, sh, sw, ph, pw, dh, dw, groups, pad_mode,
-                    sum(seg_valid) if seg_valid else cin_g)
+                    sum(seg_valid) if seg_valid else cin_g, split)
 
 
 def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
@@ -199,7 +222,7 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
     P = _lib.STRUCTS["pp_conv2d_params"]()
     x0 = inputs[0]
     n, h, w, _, _ = nhwc_view(x0)
-    P.dtype = dtype_code(x0.dtype)
+    P.dtype = _lib.CONSTS["PP_F32X2"] if spec.split else dtype_code(x0.dtype)
     P.out_dtype = dtype_code(out.dtype)
     if spec.weight.dtype != x0.dtype:
         raise TypeError("weight dtype must match the input dtype")

@@ -27,6 +27,13 @@ def _strip(sd: dict, prefix: str) -> dict:
     return {k[len(pre):]: v.float() for k, v in sd.items() if k.startswith(pre) and v.is_floating_point()}
 
 
+def _conv_spec(*args, **kw):
+    """RAFT runs on f32 tensors (the reference keeps RAFT out of its fp16 mode, propainter_inference.py).  The
+    constant-weight convolutions multiply on the f16 matrix pipe with two-term operand splits (PP_F32X2: fp32-GEMM
+    accuracy at several times the f32 MFMA rate); PP_F32_GEMM=exact selects the plain f32 MFMA kernels."""
+    return ops.make_conv_spec(*args, split=ops.f32_split_enabled(), **kw)
+
+
 def _fold_bn(w, b, p, name):
     s = p[name + ".weight"].double() / torch.sqrt(p[name + ".running_var"].double() + 1e-5)
     w2 = (w.double() * s.view(-1, 1, 1, 1)).float()
@@ -50,7 +57,7 @@ class _Encoder:
         w, b, _ = conv("conv1", "norm1")
         # 7x7 s2 on 3 channels -> im2col (k = (ky,kx,c)) + GEMM
         self.c1_kpad = ops.pad32(147)
-        self.conv1 = ops.make_conv_spec(w.permute(0, 2, 3, 1).reshape(64, 147, 1, 1), b, dt, seg_channels=[self.c1_kpad],
+        self.conv1 = _conv_spec(w.permute(0, 2, 3, 1).reshape(64, 147, 1, 1), b, dt, seg_channels=[self.c1_kpad],
                                         seg_valid=[147]).to(device)
         self.blocks = []
         cin = 64
@@ -60,16 +67,16 @@ class _Encoder:
                 w1, b1, _ = conv(pre + "conv1", pre + "norm1")
                 w2, b2, _ = conv(pre + "conv2", pre + "norm2")
                 blk = {
-                    "c1": ops.make_conv_spec(w1, b1, dt, stride=st, padding=1).to(device),
-                    "c2": ops.make_conv_spec(w2, b2, dt, padding=1).to(device),
+                    "c1": _conv_spec(w1, b1, dt, stride=st, padding=1).to(device),
+                    "c2": _conv_spec(w2, b2, dt, padding=1).to(device),
                     "down": None, "dim": dim, "stride": st,
                 }
                 if st != 1:
                     wd, bd, _ = conv(pre + "downsample.0", pre + "norm3")
-                    blk["down"] = ops.make_conv_spec(wd, bd, dt, stride=st).to(device)
+                    blk["down"] = _conv_spec(wd, bd, dt, stride=st).to(device)
                 self.blocks.append(blk)
                 cin = dim
-        self.conv2 = ops.make_conv_spec(p["conv2.weight"], p["conv2.bias"], dt).to(device)
+        self.conv2 = _conv_spec(p["conv2.weight"], p["conv2.bias"], dt).to(device)
 
     def __call__(self, frames: torch.Tensor, out: torch.Tensor, *, split_tanh_relu: bool) -> torch.Tensor:
         """frames [n,H,W,3] fp32 -> out [n,H/8,W/8,256]."""
@@ -127,13 +134,13 @@ class RaftFlow:
         u = _strip(sd, "update_block.")
 
         def spec(name, **kw):
-            return ops.make_conv_spec(u[name + ".weight"], u[name + ".bias"], dt, **kw).to(device)
+            return _conv_spec(u[name + ".weight"], u[name + ".bias"], dt, **kw).to(device)
 
         self.convc1 = spec("encoder.convc1")
         self.convc2 = spec("encoder.convc2", padding=1)
         wf1 = u["encoder.convf1.weight"]  # [128,2,7,7] -> im2col GEMM
         self.f1_kpad = ops.pad32(98)
-        self.convf1 = ops.make_conv_spec(wf1.permute(0, 2, 3, 1).reshape(128, 98, 1, 1), u["encoder.convf1.bias"], dt,
+        self.convf1 = _conv_spec(wf1.permute(0, 2, 3, 1).reshape(128, 98, 1, 1), u["encoder.convf1.bias"], dt,
                                          seg_channels=[self.f1_kpad], seg_valid=[98]).to(device)
         self.convf2 = spec("encoder.convf2", padding=1)
         self.conv = spec("encoder.conv", padding=1)
@@ -145,8 +152,8 @@ class RaftFlow:
             for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
                 w, b = u[f"gru.conv{g}{sfx}.weight"], u[f"gru.conv{g}{sfx}.bias"]
                 w_dyn = torch.cat([w[:, 0:128], w[:, 256:384]], 1)
-                self.gru[g + sfx] = ops.make_conv_spec(w_dyn, b, dt, padding=pad, seg_channels=[128, 128]).to(device)
-                self.gru_ctx[g + sfx] = ops.make_conv_spec(w[:, 128:256].contiguous(), None, dt, padding=pad).to(device)
+                self.gru[g + sfx] = _conv_spec(w_dyn, b, dt, padding=pad, seg_channels=[128, 128]).to(device)
+                self.gru_ctx[g + sfx] = _conv_spec(w[:, 128:256].contiguous(), None, dt, padding=pad).to(device)
         self.fh1 = spec("flow_head.conv1", padding=1)
         self.fh2 = spec("flow_head.conv2", padding=1)
         self.mask0 = spec("mask.0", padding=1)

@@ -32,7 +32,16 @@ extern "C" {
 
 #define PP_ABI_VERSION 1
 
-enum pp_dtype { PP_F32 = 0, PP_F16 = 1, PP_U8 = 2, PP_I32 = 3 };
+enum pp_dtype {
+  PP_F32 = 0,
+  PP_F16 = 1,
+  PP_U8 = 2,
+  PP_I32 = 3,
+  /* pp_conv2d only: f32 tensors multiplied on the f16 matrix pipe with two-term operand splits
+   * (v = h + l/2048, three MFMAs per product, fp32 accumulate: fp32-GEMM accuracy for |v| < 32752).
+   * Weights must be in the split packing described at pp_conv2d. */
+  PP_F32X2 = 4
+};
 
 enum pp_status {
   PP_OK = 0,
@@ -72,11 +81,14 @@ int64_t pp_struct_size(const char* name);
  * same [N][H][W] (segment s contributes in_C[s] channels, read with pitch in_ldc[s]).
  * Weights are pre-packed by the host (weights.py: pack_conv_weight):
  *   w[z][cout][tap = ky*kw+kx][seg][c padded to a multiple of 32], dtype = `dtype`.
+ * PP_F32X2: inputs / bias / outputs are f32; every 32-channel chunk of the f32 packing (128
+ * bytes) is replaced by 32 f16 values h = f16(w) followed by 32 f16 values l = f16((w - h) * 2048)
+ * (ops.py: split_pack_weight); same byte size and chunk order as the f32 packing.
  * gridDim.z = Z selects a group (grouped conv) or a batch item (batched GEMM):
  * every pointer advances by its *_zoff (in elements) per z.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
-  int32_t dtype;      /* PP_F32 or PP_F16: inputs and weights */
+  int32_t dtype;      /* PP_F32, PP_F16 or PP_F32X2: inputs and weights */
   int32_t out_dtype;  /* PP_F32 or PP_F16: out, aux1, aux2 */
   int32_t nseg;
   int32_t pad_mode;

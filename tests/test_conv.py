@@ -17,6 +17,16 @@ CASES = [
     (torch.float16, 1, 12, 10, [16], 6, 1, 1, 0, 1, 1, "relu"),
     (torch.float16, 1, 12, 10, [16, 8], 24, 3, 1, 1, 1, 2, "tanh"),
     (torch.float16, 1, 20, 21, [128, 128, 8], 40, 3, 1, 1, 1, 1, "leaky"),
+    # 96-channel-wide tiles (weight tile padded to whole DMA passes)
+    (torch.float32, 1, 14, 13, [16], 180, 3, 1, 1, 1, 1, "relu"),
+    (torch.float16, 1, 14, 13, [24], 96, 3, 1, 1, 1, 1, None),
+    # PP_F32X2: f32 tensors on the f16 matrix pipe (two-term operand split), every tile family
+    ("f32x2", 1, 9, 11, [8], 20, 3, 1, 1, 1, 1, None),
+    ("f32x2", 2, 9, 11, [8, 36], 70, 3, 2, 1, 1, 1, "leaky"),
+    ("f32x2", 1, 7, 13, [4], 130, (1, 5), 1, (0, 2), 1, 1, "sigmoid"),
+    ("f32x2", 1, 14, 13, [16], 180, 3, 1, 1, 1, 1, "relu"),
+    ("f32x2", 1, 12, 10, [16], 6, 1, 1, 0, 1, 1, "tanh"),
+    ("f32x2", 1, 12, 10, [16, 8], 24, 3, 1, 1, 1, 2, None),
 ]
 
 
@@ -52,12 +62,18 @@ def test_conv2d_matches_torch(be, tile):
 
 def _run_case(backend, case):
     dt, N, H, W, segC, Cout, k, s, p, d, groups, act = case
+    split = dt == "f32x2"
+    if split:
+        dt = torch.float32
     dev = backend
     g = torch.Generator().manual_seed(1234)
     x = [torch.randn(N, H, W, c * groups, generator=g).to(dt) for c in segC]
+    if split:  # wide dynamic range: tiny values exercise the scaled low term
+        x = [t * torch.logspace(-6, 2, t.shape[-1])[torch.randperm(t.shape[-1], generator=g)] for t in x]
     w = torch.randn(Cout * groups, sum(segC), *((k, k) if isinstance(k, int) else k), generator=g) * 0.1
     b = torch.randn(Cout * groups, generator=g)
-    spec = ops.make_conv_spec(w, b, dt, stride=s, padding=p, dilation=d, groups=groups, seg_channels=segC).to(dev)
+    spec = ops.make_conv_spec(w, b, dt, stride=s, padding=p, dilation=d, groups=groups, seg_channels=segC,
+                              split=split).to(dev)
     ho, wo = spec.out_hw(H, W)
     # output is a channel slice of a wider buffer: exercises the ldc / slice-view path
     buf = torch.full((N, ho, wo, Cout * groups + 8), 7.0, dtype=dt, device=dev)

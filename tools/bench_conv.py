@@ -13,6 +13,10 @@ SHAPES = [
     ("raft_gru_1x5_f32", torch.float32, 32, 45, 80, [128, 256], 128, (1, 5), 1, (0, 2)),
     ("raft_convc2_f32", torch.float32, 32, 45, 80, [256], 192, 3, 1, 1),
     ("raft_fnet_l1_f32", torch.float32, 8, 180, 320, [64], 64, 3, 1, 1),
+    ("raft_gru_1x5_f32x2", "f32x2", 32, 45, 80, [128, 256], 128, (1, 5), 1, (0, 2)),
+    ("raft_convc2_f32x2", "f32x2", 32, 45, 80, [256], 192, 3, 1, 1),
+    ("raft_fnet_l1_f32x2", "f32x2", 8, 180, 320, [64], 64, 3, 1, 1),
+    ("raft_fh2_f32x2", "f32x2", 32, 45, 80, [256], 2, 3, 1, 1),
     ("enc_conv_256_384_f16", torch.float16, 8, 90, 160, [256], 384, 3, 1, 1),
     ("dcn_offset_f16", torch.float16, 8, 90, 160, [128, 128, 8], 128, 3, 1, 1),
     ("fc1_f16", torch.float16, 1, 1, 29160, [512], 1960, 1, 1, 0),
@@ -26,9 +30,11 @@ def main():
     res = []
     for name, dt, N, H, W, segC, Cout, k, s, p in SHAPES:
         kk = (k, k) if isinstance(k, int) else k
+        split = dt == "f32x2"
+        dt = torch.float32 if split else dt
         x = [torch.randn(N, H, W, c, device=dev).to(dt) for c in segC]
         w = torch.randn(Cout, sum(segC), *kk) * 0.05
-        spec = ops.make_conv_spec(w, torch.zeros(Cout), dt, stride=s, padding=p, seg_channels=segC).to(dev)
+        spec = ops.make_conv_spec(w, torch.zeros(Cout), dt, stride=s, padding=p, seg_channels=segC, split=split).to(dev)
         ho, wo = spec.out_hw(H, W)
         out = torch.empty(N, ho, wo, Cout, device=dev, dtype=dt)
         for _ in range(3):
