@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 // LDS tile row = one 32-channel chunk = 128 bytes = 8 16-byte slots: slots 0-3 the h terms (k 0-31), 4-7 the
 // l terms, slot s stored at s ^ swz(row).  Weights are split on the host (same byte size and chunk
 // order as the f32 packing) and copied by global_load_lds; pixels are loaded as f32 (8 channels per thread), split
-// in registers and written with one ds_write_b128 per plane.  Two stages, one barrier per chunk.
+// in registers and written with one ds_write_b128 per plane.  One barrier per chunk, two chunks in flight.
 template <typename OT, int WC, int WP, int TC, int TP>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   constexpr int BC = WC * TC * 16;
@@ -594,7 +594,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   constexpr int ROWB = 128;                 // bytes per tile row
   constexpr int XPASS = (BP + 63) / 64;     // pixel passes: 4 threads per row (8 channels each), 64 rows per pass
   constexpr int WPASS = BCP / 32;           // weight passes: 8 threads per row (16 bytes each), 32 rows per pass
-  constexpr int STAGE = (BP + BCP) * ROWB;
+  // LDS: 2 pixel stages + 3 weight stages.  Pixels of chunk q+2 are in flight to registers and weights of chunk
+  // q+2 in flight to LDS while chunk q is multiplied: two chunks of latency cover per work-group.
+  constexpr int XSTAGE = BP * ROWB, WSTAGE = BCP * ROWB;
+  constexpr int NLOADS = WPASS + 2 * XPASS;  // vector-memory instructions per thread per chunk
   constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
 
   unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
@@ -649,7 +652,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
     wrow[i] = wbase + (int64_t)(co < p.Cout ? co : p.Cout - 1) * p.Kp + pcs * 4;
   }
 
-  f4 xreg[XPASS][2];
+  f4 xreg[2][XPASS][2];  // two chunks in flight (hidden loads: valid only after the counted wait in store_x)
+  int xok[2] = {0, 0};   // validity bits of the half octets (2 per pass) of each register set
 
   int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
   const float* it_base = reinterpret_cast<const float*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
@@ -684,14 +688,16 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
 
   // next chunk of the K iterator: weights -> LDS stage `buf` (DMA), pixels -> registers (unconditional loads;
   // out-of-image taps and padded channels read a safe address and are zeroed by a select)
-  auto fetch = [&](int buf) {
-    unsigned char* wt = smem + buf * STAGE + BP * ROWB;
+  auto fetch = [&](int wbuf, auto par) {
+    constexpr int P = decltype(par)::value;
+    unsigned char* wt = smem + 2 * XSTAGE + wbuf * WSTAGE;
 #pragma unroll
     for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + (int64_t)it_q * 32, wt + (i * 256 + wave * 64) * 16);
     const int c0 = it_rem * 32 + xj * 8;
     const int dy = it_ky * p.dh, dx = it_kx * p.dw;
     const int64_t tapoff = (int64_t)dy * p.W + dx;
     const float* cbase = it_base + c0;
+    int okbits = 0;
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
       const int y = (pyx[i] >> 16) + dy, x = (int)(short)(pyx[i] & 0xffff) + dx;
@@ -708,26 +714,31 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
       // segment channel counts are multiples of 4: each half octet is either fully valid or padding
       const bool ok0 = ok && (c0 < it_C), ok1 = ok && (c0 + 4 < it_C);
       const float* src = ok0 ? cbase + pix * it_ldc : it_base;
-      f4 v0 = *reinterpret_cast<const f4*>(src);
-      f4 v1 = *reinterpret_cast<const f4*>(src + (ok1 ? 4 : 0));
-      if (!ok0) v0 = f4{0.f, 0.f, 0.f, 0.f};
-      if (!ok1) v1 = f4{0.f, 0.f, 0.f, 0.f};
-      xreg[i][0] = v0;
-      xreg[i][1] = v1;
+      gload16_hidden(xreg[P][i][0], src);
+      gload16_hidden(xreg[P][i][1], src + (ok1 ? 4 : 0));
+      okbits |= (ok0 ? 1 : 0) << (2 * i) | (ok1 ? 2 : 0) << (2 * i);
     }
+    xok[P] = okbits;
     advance();
   };
   // split the fetched pixels (h: round toward zero, saturating; l: the exact remainder * 2048, round to nearest)
   // and write one 16-byte octet per plane
-  auto store_x = [&](int buf) {
-    unsigned char* xs = smem + buf * STAGE;
+  // `later` = vector-memory instructions this thread issued after the loads of register set P (0 or NLOADS): waiting
+  // until only those are outstanding retires, in order, this chunk's weight copies and pixel loads.
+  auto store_x = [&](auto par, auto later) {
+    constexpr int P = decltype(par)::value;
+    unsigned char* xs = smem + P * XSTAGE;
+    wait_vmcnt_hidden<decltype(later)::value>();
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
       if (BP % 64 != 0 && xrow0 + i * 64 >= BP) continue;
+      f4 v[2] = {xreg[P][i][0], xreg[P][i][1]};
+      if (!((xok[P] >> (2 * i)) & 1)) v[0] = f4{0.f, 0.f, 0.f, 0.f};
+      if (!((xok[P] >> (2 * i)) & 2)) v[1] = f4{0.f, 0.f, 0.f, 0.f};
       h8 h, l;
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
-        const float c0 = xreg[i][e >> 2][e & 3], c1 = xreg[i][e >> 2][(e & 3) + 1];
+        const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
         const h2 hh = cvt_pkrtz_f16(c0, c1);
         h[e] = hh[0];
         h[e + 1] = hh[1];
@@ -754,9 +765,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   const int roff_h = (fgrp ^ swz(frow)) << 4;
   const int roff_l = ((fgrp + 4) ^ swz(frow)) << 4;
 
-  auto compute = [&](int buf) {
-    const unsigned char* xs = smem + buf * STAGE + (wp * TP * 16 + frow) * ROWB;
-    const unsigned char* ws = smem + buf * STAGE + BP * ROWB + (wc * TC * 16 + frow) * ROWB;
+  auto compute = [&](int xbuf, int wbuf) {
+    const unsigned char* xs = smem + xbuf * XSTAGE + (wp * TP * 16 + frow) * ROWB;
+    const unsigned char* ws = smem + 2 * XSTAGE + wbuf * WSTAGE + (wc * TC * 16 + frow) * ROWB;
     h8 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
     for (int a = 0; a < TC; ++a) {
@@ -784,15 +795,34 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   };
 
   const int nstages = p.nchunks;
-  fetch(0);
-  store_x(0);
-  __syncthreads();
-  for (int qs = 0; qs < nstages; ++qs) {
-    const int buf = qs & 1;
-    if (qs + 1 < nstages) fetch(buf ^ 1);
-    compute(buf);
-    if (qs + 1 < nstages) store_x(buf ^ 1);
-    __syncthreads();  // also drains the weight copies (vmcnt(0))
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+  fetch(0, P0{});
+  if (nstages > 1) fetch(1, P1{});
+  typedef std::integral_constant<int, 0> L0;
+  typedef std::integral_constant<int, NLOADS> LN;
+  if (nstages > 1) store_x(P0{}, LN{}); else store_x(P0{}, L0{});
+  pp_wait_lgkm0();
+  pp_barrier();
+  // iteration qs (parity P = qs & 1): pixels of chunk qs are in LDS stage P, weights in stage qs % 3; chunk qs+1 is in
+  // registers set 1-P / in flight to weight stage (qs+1) % 3.
+  int w0 = 0;  // qs % 3
+  auto iteration = [&](int qs, auto par) {
+    constexpr int P = decltype(par)::value;
+    typedef std::integral_constant<int, 1 - P> Q;
+    const int w1 = w0 == 2 ? 0 : w0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;
+    if (qs + 2 < nstages) fetch(w2, par);  // register set P was stored to LDS one iteration ago
+    compute(P, w0);
+    if (qs + 1 < nstages) {
+      if (qs + 2 < nstages) store_x(Q{}, LN{}); else store_x(Q{}, L0{});
+    }
+    pp_wait_lgkm0();
+    pp_barrier();  // bare barrier: the copies of chunk qs+2 stay in flight across it
+    w0 = w1;
+  };
+  for (int qs = 0; qs < nstages; qs += 2) {
+    iteration(qs, P0{});
+    if (qs + 1 < nstages) iteration(qs + 1, P1{});
   }
 
   EpiCtx<OT> e;
@@ -818,7 +848,7 @@ static int launch_split_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
   constexpr int BCP = (BC + 31) / 32 * 32;
-  const size_t smem = (size_t)2 * (BP + BCP) * 128;
+  const size_t smem = (size_t)(2 * BP + 3 * BCP) * 128;
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_split_kernel<OT, WC, WP, TC, TP>), smem), true);
   (void)lds_ok;

@@ -65,6 +65,22 @@ template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// A 16-byte global load the compiler does not see (inline asm): next to global_load_lds copies hipcc would wait
+// vmcnt(0) at the first use of an ordinary load's result and drain the whole pipeline.  The destination is NOT valid
+// until wait_vmcnt_hidden<N>() has been executed (the caller counts the vector-memory queue by hand).
+__device__ __forceinline__ void gload16_hidden(f4& dst, const void* src) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+// counted wait for hidden loads + a scheduling barrier: no instruction (in particular no consumer of a hidden
+// load's destination) is moved across it.  The destinations are defined once and only read afterwards, so the
+// register allocator has no reason to copy them while the data is in flight (audited in the -save-temps output).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_hidden() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// LDS writes / reads of this wave retired (what __syncthreads() would wait for besides vmcnt)
+__device__ __forceinline__ void pp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void pp_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -79,6 +95,10 @@ inline void glds16(const void* g, void* lds_wave_base) {
 static const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
 template <int N>
 inline void pp_wait_vmcnt() {}
+inline void pp_wait_lgkm0() {}
+inline void gload16_hidden(f4& dst, const void* src) { memcpy(&dst, src, 16); }
+template <int N>
+inline void wait_vmcnt_hidden() {}
 inline void pp_barrier() { pp_emu::barrier(); }
 inline f4 mfma_16x16x32_f16(h8 a, h8 b, f4 c) {
   struct Slot {
