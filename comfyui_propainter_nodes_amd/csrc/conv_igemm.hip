@@ -291,10 +291,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   piece_t xreg[KC][XPASS];
   piece_t wreg[KC][WPASS];
 
-  // K iterator (wave-uniform): chunk -> (tap ky,kx ; segment ; 32-channel chunk inside the segment).
+  // K iterator (wave-uniform): (segment ; channel chunk inside the segment ; tap ky,kx) with the TAP INNERMOST:
+  // the taps of one channel chunk re-read the same 128-byte lines of neighbouring pixels back to back (L1/L2 hits).
+  // With the tap outermost a work-group streams all channels between two visits of a line, and the ~100 resident
+  // work-groups of an XCD push each other's lines out of the 4 MiB L2 (every tap then refetches over the fabric).
+  // The packed weights keep their [tap][segment][channel] order: the chunk's row offset is computed, not streamed.
   // Advanced incrementally (no integer divisions); segment parameters are picked with constant
   // indices only, so the kernel-argument arrays stay in SGPRs instead of being copied to scratch.
-  int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
+  int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0, it_sbase = 0;
+  auto it_woff = [&]() { return (it_ky * p.kw + it_kx) * p.chunks_per_tap * 32 + it_sbase + it_rem * BK; };
   const T* it_base = reinterpret_cast<const T*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
   int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0] * CM;
   auto select_segment = [&](int seg) {
@@ -310,16 +315,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   };
   auto advance = [&]() {
     ++it_q;
-    if (++it_rem == it_chunks) {
-      it_rem = 0;
-      if (++it_seg == p.nseg) {
-        it_seg = 0;
-        if (++it_kx == p.kw) {
-          it_kx = 0;
-          ++it_ky;
+    if (++it_kx == p.kw) {
+      it_kx = 0;
+      if (++it_ky == p.kh) {
+        it_ky = 0;
+        if (++it_rem == it_chunks) {
+          it_rem = 0;
+          it_sbase += it_chunks * BK;
+          if (p.nseg > 1) select_segment(++it_seg);
         }
       }
-      select_segment(it_seg);
     }
   };
 
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     }
 #pragma unroll
     for (int i = 0; i < WPASS; ++i) {
-      piece_t v = *reinterpret_cast<const piece_t*>(wrow[i] + (int64_t)(live ? it_q : 0) * BK);
+      piece_t v = *reinterpret_cast<const piece_t*>(wrow[i] + (live ? it_woff() : 0));
       if (KC > 1 && !live) {
 #pragma unroll
         for (int e = 0; e < EPP; ++e) v[e] = (T)0;
@@ -397,8 +402,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
       const void* src = ok ? static_cast<const void*>(sbase + pix * ldc + c0) : static_cast<const void*>(pp_zero16);
       glds16(src, xt + (i * 256 + wave * 64) * EPP);
     }
+    const int woff = it_woff();
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + (int64_t)it_q * BK, wt + (i * 256 + wave * 64) * EPP);
+    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * EPP);
     advance();
   };
   auto dma_stage = [&](int buf) { static_for<KC>([&](auto kci) { dma_chunk(buf, kci); }); };
@@ -655,7 +661,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   f4 xreg[2][XPASS][2];  // two chunks in flight (hidden loads: valid only after the counted wait in store_x)
   int xok[2] = {0, 0};   // validity bits of the half octets (2 per pass) of each register set
 
-  int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0;
+  // K iterator: tap innermost (see conv_igemm_kernel)
+  int it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0, it_sbase = 0;
+  auto it_woff = [&]() { return (it_ky * p.kw + it_kx) * p.chunks_per_tap * 32 + it_sbase + it_rem * 32; };
   const float* it_base = reinterpret_cast<const float*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
   int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0];
   auto select_segment = [&](int seg) {
@@ -670,18 +678,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
     }
   };
   auto advance = [&]() {
-    ++it_q;
-    if (++it_rem == it_chunks) {
-      it_rem = 0;
-      if (p.nseg > 1 || p.kh * p.kw > 1) {
-        if (++it_seg == p.nseg) {
-          it_seg = 0;
-          if (++it_kx == p.kw) {
-            it_kx = 0;
-            ++it_ky;
-          }
+    if (++it_kx == p.kw) {
+      it_kx = 0;
+      if (++it_ky == p.kh) {
+        it_ky = 0;
+        if (++it_rem == it_chunks) {
+          it_rem = 0;
+          it_sbase += it_chunks * 32;
+          if (p.nseg > 1) select_segment(++it_seg);
         }
-        if (p.nseg > 1) select_segment(it_seg);
       }
     }
   };
@@ -691,8 +696,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   auto fetch = [&](int wbuf, auto par) {
     constexpr int P = decltype(par)::value;
     unsigned char* wt = smem + 2 * XSTAGE + wbuf * WSTAGE;
+    const int woff = it_woff();
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + (int64_t)it_q * 32, wt + (i * 256 + wave * 64) * 16);
+    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * 16);
     const int c0 = it_rem * 32 + xj * 8;
     const int dy = it_ky * p.dh, dx = it_kx * p.dw;
     const int64_t tapoff = (int64_t)dy * p.W + dx;

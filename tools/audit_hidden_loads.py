@@ -1,26 +1,98 @@
-"""Audit of the -save-temps ISA of conv_igemm.hip: no instruction may touch the destination registers of a hidden
-(inline-asm) global load between the load and the next counted s_waitcnt vmcnt.  Usage: hipcc ... -save-temps=obj, then run."""
+"""CFG-aware audit of the -save-temps ISA of conv_igemm.hip: between a hidden (inline-asm) global load and the next
+s_waitcnt vmcnt on every execution path, no instruction may read or write the load's destination registers (hipcc
+does not know they are in flight: a register-allocator copy or reuse there would silently corrupt the tile).
+
+Usage: hipcc ... -c conv_igemm.hip -save-temps=obj ; python tools/audit_hidden_loads.py <file.s>"""
 import re
-s=open('/tmp/conv_igemm-hip-amdgcn-amd-amdhsa-gfx950.s').read()
-bad=0
-for m in re.finditer(r'^(_ZN2pp17conv_split_kernel\w+):', s, flags=re.M):
-    name=m.group(1)
-    a=m.start(); b=s.index('.Lfunc_end',a)
-    body=[l.strip() for l in s[a:b].split('\n')]
-    pending={}
-    for i,l in enumerate(body):
-        if l.startswith('global_load_dwordx4') and body[i-1].startswith(';;#ASMSTART'):
-            mm=re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]',l)
-            for r in range(int(mm.group(1)),int(mm.group(2))+1): pending[r]=i
-            continue
-        if l.startswith('s_waitcnt') and 'vmcnt' in l:
-            pending.clear(); continue
-        if not l or l[0] in '.;': continue
-        regs=set()
-        for mm in re.finditer(r'v\[(\d+):(\d+)\]',l): regs.update(range(int(mm.group(1)),int(mm.group(2))+1))
-        for mm in re.finditer(r'\bv(\d+)\b',l): regs.add(int(mm.group(1)))
-        hit=regs & set(pending)
-        if hit:
-            bad+=1
-            if bad<12: print(name[-36:], i, l, sorted(hit)[:4])
-print('suspicious', bad)
+import sys
+
+
+def regs_of(line):
+    regs = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", line):
+        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", line):
+        regs.add(int(m.group(1)))
+    return regs
+
+
+def audit_function(name, lines):
+    # split into basic blocks
+    blocks, cur, label = {}, [], "entry"
+    order = []
+    for ln in lines:
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            blocks[label] = cur
+            order.append(label)
+            label, cur = m.group(1), []
+        else:
+            cur.append(ln.strip())
+    blocks[label] = cur
+    order.append(label)
+    succ = {}
+    for i, lb in enumerate(order):
+        ins = [l for l in blocks[lb] if l and l[0] not in ".;"]
+        s = set()
+        fall = True
+        for l in ins:
+            if l.startswith("s_cbranch"):
+                s.add(l.split()[-1])
+            elif l.startswith("s_branch"):
+                s.add(l.split()[-1])
+                fall = False
+            elif l.startswith("s_endpgm"):
+                fall = False
+        if fall and i + 1 < len(order):
+            s.add(order[i + 1])
+        succ[lb] = s
+    entry = {lb: frozenset() for lb in order}
+    bad = []
+    changed = True
+    rounds = 0
+    while changed and rounds < 50:
+        changed = False
+        rounds += 1
+        bad = []
+        for lb in order:
+            pending = set(entry[lb])
+            body = blocks[lb]
+            for i, l in enumerate(body):
+                if not l or l[0] in ".;":
+                    continue
+                if l.startswith("global_load_dwordx4") and i > 0 and body[i - 1].startswith(";;#ASMSTART"):
+                    m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", l)
+                    addr = regs_of(l.split(",", 1)[1])
+                    if addr & pending:
+                        bad.append((lb, l))
+                    pending.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                    continue
+                if l.startswith("s_waitcnt") and "vmcnt" in l:
+                    pending.clear()
+                    continue
+                if regs_of(l) & pending:
+                    bad.append((lb, l))
+            for t in succ[lb]:
+                if t in entry and not pending <= entry[t]:
+                    entry[t] = frozenset(entry[t] | pending)
+                    changed = True
+    return bad
+
+
+def main(path):
+    s = open(path).read()
+    total = 0
+    for m in re.finditer(r"^(_ZN2pp\w*conv_split_kernel\w+):", s, flags=re.M):
+        a = m.end()
+        b = s.index(".Lfunc_end", a)
+        bad = audit_function(m.group(1), s[a:b].split("\n"))
+        total += len(bad)
+        print(m.group(1)[-40:], "violations:", len(bad))
+        for lb, l in bad[:6]:
+            print("   ", lb, l)
+    print("total violations", total)
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else "/tmp/conv_igemm-hip-amdgcn-amd-amdhsa-gfx950.s"))
