@@ -36,7 +36,12 @@ sys.path.insert(0, str(ROOT))
 
 CFG = dict(T=80, H=360, W=640, neighbor_length=10, ref_stride=10, subvideo_length=80, raft_iter=20,
            mask_dilates=5, flow_mask_dilates=8)
-PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+# MI355X dense MFMA peaks (MI355X_MICROARCH.md).  "f32x2" = f32 convolutions computed as three f16 MFMA products per
+# multiply-add (PP_F32X2 operand split): its ceiling for ALGORITHMIC flops is a third of the f16 peak.
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32x2": 2500.0 / 3.0}
+KERNEL_NAME = {"f32": "conv_igemm_kernel<float> (pp_conv2d, f32 MFMA implicit GEMM)",
+               "f16": "conv_igemm_kernel<f16> (pp_conv2d, f16 MFMA implicit GEMM)",
+               "f32x2": "conv_split_kernel (pp_conv2d PP_F32X2: f32 implicit GEMM as 3 f16 MFMA products)"}
 
 
 def make_inputs(T, H, W, mask_dilates, flow_mask_dilates, seed=1234):
@@ -152,13 +157,16 @@ def main():
     roofline = None
     traffic = None
     tfile = ROOT / "profiles" / "r01_traffic.json"
-    if dom == "f32" and tfile.exists():  # PMC passes cannot run inside bench.py: the committed rocprofv3 result
-        traffic = json.loads(tfile.read_text())["hbm_bytes_per_launch"]
+    if tfile.exists():  # PMC passes cannot run inside bench.py: the committed rocprofv3 result of the same kernel
+        fam = json.loads(tfile.read_text()).get("families", {})
+        if dom in fam:
+            traffic = fam[dom]["hbm_bytes_per_launch"]
     if dom:
         d = prof[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        roofline = {"kernel": f"conv_igemm_kernel<{dom}> (pp_conv2d, MFMA implicit GEMM)", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dom], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dom], 4),
+        roofline = {"kernel": KERNEL_NAME[dom], "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": round(PEAK_TFLOPS[dom], 1), "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS[dom], 4),
                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
                     "algorithmic_bytes_per_launch": d["bytes"] / d["n"], "launches": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / d["n"], 2),
                     "flops_per_launch": d["flops"] / d["n"], "share_of_step_ms": round(d["ms"], 1),
@@ -168,7 +176,7 @@ def main():
     line = {
         "metric": "inpainted frames/sec end-to-end, 640x360 neighbor=10", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 (RAFT f32), fp32 accumulate",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 (RAFT: f32 tensors, f16x2-split MFMA products), fp32 accumulate",
         "data": f"synthetic clip (seeded texture + sinusoidal motion, centre box mask); weights: {prov}",
         "config": {"workload": f"{T}-frame 640x360 clip, neighbor_length 10, ref_stride 10, subvideo_length 80, raft_iter 20, "
                                f"fp16 enable (BASELINE.json configs[{1 if world == 1 else 3}])", "frames_per_gpu": T // world,

@@ -26,6 +26,10 @@
 
 namespace pp {
 
+// helper lambdas of the kernels must never become real calls (a call makes the kernel-argument struct and the
+// register arrays addressable: both would move to scratch memory)
+#define PP_INLINE_LAMBDA __attribute__((always_inline))
+
 struct ConvK {
   const void* in_ptr[PP_MAX_SEG];
   int in_C[PP_MAX_SEG];
@@ -299,10 +303,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   // Advanced incrementally (no integer divisions); segment parameters are picked with constant
   // indices only, so the kernel-argument arrays stay in SGPRs instead of being copied to scratch.
   int it_q = 0, it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0, it_sbase = 0;
-  auto it_woff = [&]() { return (it_ky * p.kw + it_kx) * p.chunks_per_tap * 32 + it_sbase + it_rem * BK; };
+  auto it_woff = [&]() PP_INLINE_LAMBDA { return (it_ky * p.kw + it_kx) * p.chunks_per_tap * 32 + it_sbase + it_rem * BK; };
   const T* it_base = reinterpret_cast<const T*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
   int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0] * CM;
-  auto select_segment = [&](int seg) {
+  auto select_segment = [&](int seg) PP_INLINE_LAMBDA {
 #pragma unroll
     for (int s = 0; s < PP_MAX_SEG; ++s) {
       if (seg == s) {
@@ -313,7 +317,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
       }
     }
   };
-  auto advance = [&]() {
+  auto advance = [&]() PP_INLINE_LAMBDA {
     ++it_q;
     if (++it_kx == p.kw) {
       it_kx = 0;
@@ -331,7 +335,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   // global -> registers for the next chunk of the K iterator.  Every load is UNCONDITIONAL (a predicated
   // load costs an exec-mask branch per piece): out-of-image taps / padded channels read a safe address and
   // are zeroed by a select; tile rows past M / Cout read a clamped row, their results are never stored.
-  auto load_chunk = [&](auto kci) {
+  auto load_chunk = [&](auto kci) PP_INLINE_LAMBDA {
     constexpr int kc = decltype(kci)::value;
     const bool live = (KC == 1) || (it_q < p.nchunks * CM);
     const int c0 = it_rem * BK + pcs * EPP;
@@ -372,11 +376,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     }
     if (live) advance();
   };
-  auto load_stage = [&]() { static_for<KC>([&](auto kci) { load_chunk(kci); }); };
+  auto load_stage = [&]() PP_INLINE_LAMBDA { static_for<KC>([&](auto kci) { load_chunk(kci); }); };
 
   // DMA variant of load_chunk + store: the same source addresses, but every wave-instruction copies 64 x 16 bytes
   // straight into the lane-linear LDS image (slot index = i*256 + tid) of stage `buf`; zeros come from pp_zero16.
-  auto dma_chunk = [&](int buf, auto kci) {
+  auto dma_chunk = [&](int buf, auto kci) PP_INLINE_LAMBDA {
     constexpr int kc = decltype(kci)::value;
     T* xt = smem + buf * STAGE + kc * (BP + BCP) * LDK;
     T* wt = xt + BP * LDK;
@@ -407,9 +411,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
     for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * EPP);
     advance();
   };
-  auto dma_stage = [&](int buf) { static_for<KC>([&](auto kci) { dma_chunk(buf, kci); }); };
+  auto dma_stage = [&](int buf) PP_INLINE_LAMBDA { static_for<KC>([&](auto kci) { dma_chunk(buf, kci); }); };
 
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf) PP_INLINE_LAMBDA {
     static_for<KC>([&](auto kci) {
       constexpr int kc = decltype(kci)::value;
       T* xs = smem + buf * STAGE + kc * (BP + BCP) * LDK;
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   }
   __syncthreads();
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) PP_INLINE_LAMBDA {
     static_for<KC>([&](auto kci) {
       constexpr int kc = decltype(kci)::value;
       const T* xt = smem + buf * STAGE + kc * (BP + BCP) * LDK;
@@ -622,7 +626,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   //    distinct 16-byte slots of the 256-byte bank row;
   //  - pixel writes (ds_write_b128, 8-lane groups = 2 rows x 4 slots of one plane): the odd row's plane lives in
   //    the other half of the 128-byte row, so the 8 lanes cover 8 distinct slots.
-  auto swz = [](int r) { return ((r >> 1) & 7) ^ ((r & 1) << 2); };
+  auto swz = [](int r) PP_INLINE_LAMBDA { return ((r >> 1) & 7) ^ ((r & 1) << 2); };
 
   // weights: lane-linear DMA image, LDS slot pc of row wrow0 holds source piece pc ^ swz
   const int pc = tid & 7;
@@ -663,10 +667,10 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
 
   // K iterator: tap innermost (see conv_igemm_kernel)
   int it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0, it_sbase = 0;
-  auto it_woff = [&]() { return (it_ky * p.kw + it_kx) * p.chunks_per_tap * 32 + it_sbase + it_rem * 32; };
+  auto it_woff = [&]() PP_INLINE_LAMBDA { return (it_ky * p.kw + it_kx) * p.chunks_per_tap * 32 + it_sbase + it_rem * 32; };
   const float* it_base = reinterpret_cast<const float*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
   int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0];
-  auto select_segment = [&](int seg) {
+  auto select_segment = [&](int seg) PP_INLINE_LAMBDA {
 #pragma unroll
     for (int s = 0; s < PP_MAX_SEG; ++s) {
       if (seg == s) {
@@ -677,7 +681,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
       }
     }
   };
-  auto advance = [&]() {
+  auto advance = [&]() PP_INLINE_LAMBDA {
     if (++it_kx == p.kw) {
       it_kx = 0;
       if (++it_ky == p.kh) {
@@ -693,7 +697,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
 
   // next chunk of the K iterator: weights -> LDS stage `buf` (DMA), pixels -> registers (unconditional loads;
   // out-of-image taps and padded channels read a safe address and are zeroed by a select)
-  auto fetch = [&](int wbuf, auto par) {
+  auto fetch = [&](int wbuf, auto par) PP_INLINE_LAMBDA {
     constexpr int P = decltype(par)::value;
     unsigned char* wt = smem + 2 * XSTAGE + wbuf * WSTAGE;
     const int woff = it_woff();
@@ -731,7 +735,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   // and write one 16-byte octet per plane
   // `later` = vector-memory instructions this thread issued after the loads of register set P (0 or NLOADS): waiting
   // until only those are outstanding retires, in order, this chunk's weight copies and pixel loads.
-  auto store_x = [&](auto par, auto later) {
+  auto store_x = [&](auto par, auto later) PP_INLINE_LAMBDA {
     constexpr int P = decltype(par)::value;
     unsigned char* xs = smem + P * XSTAGE;
     wait_vmcnt_hidden<decltype(later)::value>();
@@ -771,7 +775,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   const int roff_h = (fgrp ^ swz(frow)) << 4;
   const int roff_l = ((fgrp + 4) ^ swz(frow)) << 4;
 
-  auto compute = [&](int xbuf, int wbuf) {
+  auto compute = [&](int xbuf, int wbuf) PP_INLINE_LAMBDA {
     const unsigned char* xs = smem + xbuf * XSTAGE + (wp * TP * 16 + frow) * ROWB;
     const unsigned char* ws = smem + 2 * XSTAGE + wbuf * WSTAGE + (wc * TC * 16 + frow) * ROWB;
     h8 ah[TC], al[TC], bh[TP], bl[TP];
@@ -813,7 +817,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   // iteration qs (parity P = qs & 1): pixels of chunk qs are in LDS stage P, weights in stage qs % 3; chunk qs+1 is in
   // registers set 1-P / in flight to weight stage (qs+1) % 3.
   int w0 = 0;  // qs % 3
-  auto iteration = [&](int qs, auto par) {
+  auto iteration = [&](int qs, auto par) PP_INLINE_LAMBDA {
     constexpr int P = decltype(par)::value;
     typedef std::integral_constant<int, 1 - P> Q;
     const int w1 = w0 == 2 ? 0 : w0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;

@@ -285,7 +285,7 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
         P.pre_add_ldc = nhwc_view(pre_add)[4]
     if CONV_PROFILE is not None and out.is_cuda:
         flops = 2.0 * n * ho * wo * spec.cout * g * spec.cin_valid * spec.kh * spec.kw
-        key = "f16" if x0.dtype == torch.float16 else "f32"
+        key = "f16" if x0.dtype == torch.float16 else ("f32x2" if spec.split else "f32")
         if CONV_PROFILE.detailed:
             key += f"|k{spec.kh}x{spec.kw} cin{spec.cin_valid} cout{spec.cout} g{g} M{n * ho * wo}"
         # algorithmic HBM bytes: every input / weight / epilogue operand read once, the output written once

@@ -20,6 +20,10 @@ CASES = [
     # 96-channel-wide tiles (weight tile padded to whole DMA passes)
     (torch.float32, 1, 14, 13, [16], 180, 3, 1, 1, 1, 1, "relu"),
     (torch.float16, 1, 14, 13, [24], 96, 3, 1, 1, 1, 1, None),
+    # 49 taps: the general (per-tap bounds test) gather instead of the 32-bit tap-mask fast path
+    (torch.float16, 1, 20, 23, [16], 40, 7, 3, 3, 1, 1, None),
+    (torch.float32, 1, 11, 12, [8], 24, 7, 1, 3, 1, 1, "relu"),
+    ("f32x2", 1, 11, 12, [8], 24, 7, 1, 3, 1, 1, "relu"),
     # PP_F32X2: f32 tensors on the f16 matrix pipe (two-term operand split), every tile family
     ("f32x2", 1, 9, 11, [8], 20, 3, 1, 1, 1, 1, None),
     ("f32x2", 2, 9, 11, [8, 36], 70, 3, 2, 1, 1, 1, "leaky"),

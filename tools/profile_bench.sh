@@ -10,5 +10,7 @@ timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $S -o fetch -- python b
 python tools/rocpd_pmc_stats.py $S/fetch_results.db FETCH_SIZE $O/pmc_fetch_size.json > /dev/null
 timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $S -o write -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/write.log 2>&1
 python tools/rocpd_pmc_stats.py $S/write_results.db WRITE_SIZE $O/pmc_write_size.json > /dev/null
+python tools/make_traffic.py $O/pmc_fetch_size.json $O/pmc_write_size.json $O/traffic.json conv_split_kernel=f32x2 conv_igemm_kernelIDF16_=f16 'conv_igemm_kernel<float'=f32 > /dev/null
+cp $O/traffic.json profiles/r01_traffic.json   # bench.py reads it for roofline.traffic
 timeout 200 python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 head -12 $O/kernel_stats.md; tail -c 400 $O/bench.json
