@@ -4,6 +4,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_final; mkdir -p $O; S=/tmp/pp_prof; mkdir -p $S
+timeout 240 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 150 rocprofv3 --kernel-trace --stats -d $S -o trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/trace.log 2>&1
 python tools/rocpd_kernel_stats.py $S/trace_results.db $O/kernel_stats.md > /dev/null
 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $S -o fetch -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/fetch.log 2>&1
