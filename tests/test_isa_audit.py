@@ -1,0 +1,33 @@
+"""The PP_F32X2 convolution hides its pixel loads from hipcc's s_waitcnt bookkeeping (inline asm, counted by hand):
+the emitted gfx950 ISA must not touch a load's destination registers before the counted wait on ANY path, must not
+use scratch memory and must not contain calls.  Cross-compiles on CPU (no GPU needed)."""
+import re
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists(), reason="no hipcc")
+def test_hidden_loads_are_never_touched_in_flight(tmp_path):
+    import audit_hidden_loads as A
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = ROOT / "comfyui_propainter_nodes_amd" / "csrc" / "conv_igemm.hip"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{ROOT / 'include'}",
+           f"-I{src.parent}", "-c", str(src), "-o", str(tmp_path / "conv.o"), "-save-temps=obj"]
+    subprocess.run(cmd, check=True, cwd=tmp_path, capture_output=True)
+    asm = next(tmp_path.glob("*gfx950*.s"))
+    text = asm.read_text()
+    kernels = re.findall(r"^(_ZN2pp\w*conv_split_kernel\w+):", text, flags=re.M)
+    assert len(kernels) == 7  # one per tile variant
+    assert "global_load_lds_dwordx4" in text and ";;#ASMSTART" in text
+    assert A.main(str(asm)) == 0
+    assert "s_swappc" not in text  # no real calls: helper lambdas are always inlined
+    scratch = re.findall(r"\.private_segment_fixed_size: (\d+)", text)
+    assert scratch and all(int(v) == 0 for v in scratch), scratch
