@@ -7,15 +7,19 @@
 // channels of one pixel*, i.e. one 8-byte (f16) / 16-byte (f32) channels-last store.
 //
 // Work-group = 256 threads = 4 waves arranged WC x WP; each wave owns (TC*16) x (TP*16).
-// K is walked in chunks of 32 channels of one (tap, segment); both tiles are staged
-// global -> VGPR -> LDS (rows padded by one 16-byte access to break the power-of-two
-// pitch), double-buffered, one barrier per chunk.
+// K is walked in chunks of 32 channels in (segment, channel chunk, tap) order -- the tap innermost, so that the
+// taps of one chunk re-read the same lines of neighbouring pixels back to back.  One barrier per chunk.
+// Staging: tiles whose rows fill whole 64-lane passes are copied by global_load_lds into a lane-linear LDS image
+// (XOR swizzle applied to the SOURCE address), f16 / f32-half-chunk tiles in a 3-stage ring with counted
+// s_waitcnt vmcnt(N) and a bare s_barrier (two chunks in flight); the other tiles go global -> VGPR -> LDS,
+// double-buffered.  LDS rows are unpadded; 16-byte piece p of row r sits at p ^ swz(r) (conflict-free for the
+// 16-lane service groups of ds_read_b128 on gfx950).
 //
 //   f16 : v_mfma_f32_16x16x32_f16, one MFMA per (tc,tp) per chunk.
-//   f32 : v_mfma_f32_16x16x4_f32 (exact f32).  A lane reads a float4 = k 4g..4g+3 of a
-//         16-wide sub-chunk and feeds element j to MFMA step j; lane group g therefore
-//         supplies k = 4g + j at step j for BOTH operands, which only permutes the
-//         summation order.
+//   f32 : v_mfma_f32_32x32x2_f32 (wave tile a multiple of 32x32) or v_mfma_f32_16x16x4_f32: exact f32 products.
+//         A lane reads a float4 = 4 consecutive k and feeds element j to MFMA step j for BOTH operands, which
+//         only permutes the summation order.
+//   f32 on the f16 pipe (PP_F32X2): conv_split_kernel below.
 #include "pp_device.h"
 #include "pp_host.h"
 

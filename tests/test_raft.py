@@ -44,3 +44,23 @@ def test_raft_pair_batching_is_chunk_invariant(hip_lib):
     a = raft.RaftFlow(sds["raft"], "cuda:0")(frames, 2)
     b = raft.RaftFlow(sds["raft"], "cuda:0", max_volume_bytes=1, enc_chunk=2)(frames, 2)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+def test_raft_split_gemm_matches_exact_f32_gemm(hip_lib, monkeypatch):
+    """PP_F32X2 (f32 convolutions as three f16 MFMA products per multiply-add, the default) against the exact f32
+    MFMA kernels (PP_F32_GEMM=exact) on the same clip: both must sit inside the fixture tolerance of each other."""
+    sds = weights.synth_state_dicts(0)
+    image, _ = synth.synthetic_clip(4, 128, 144)
+    frames = (image * 2 - 1).cuda()
+    monkeypatch.setenv("PP_F32_GEMM", "exact")
+    exact = raft.RaftFlow(sds["raft"], "cuda:0")
+    assert not exact.convc1.split
+    fe, be = exact(frames, 6)
+    monkeypatch.setenv("PP_F32_GEMM", "split")
+    split = raft.RaftFlow(sds["raft"], "cuda:0")
+    assert split.convc1.split and split.gru["z1"].split
+    fs, bs = split(frames, 6)
+    assert torch.isfinite(fs).all() and torch.isfinite(bs).all()
+    assert (fs - fe).abs().max().item() < 1e-3, (fs - fe).abs().max().item()
+    assert (bs - be).abs().max().item() < 1e-3
