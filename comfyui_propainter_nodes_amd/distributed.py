@@ -5,7 +5,9 @@ The reference already cuts a long clip into sub-videos of `subvideo_length` fram
 +-ref_stride*(ref_num//2) frames around a window for reference frames (:36-58).  Those chunks are the
 shards: rank r owns a contiguous run of sub-video chunks, i.e. frames [F0, F1).  Per rank:
 
-  A  RAFT on its frames (+5-flow halo, recomputed locally), flow completion of its chunks
+  A  RAFT on the frame pairs it owns
+  x0 all_gather of the raw RAFT flows at the seams (5 per side: the flow-completion halos)
+  A' flow completion of its chunks
   x1 all_gather of the completed flows                       (RCCL over xGMI / gloo in tests)
   B  image propagation of its chunks (+10-frame halo from x1), blend, encoder on its frames
   x2 all_gather of encoder features + updated masks
@@ -88,7 +90,8 @@ class ShardPlan:
         return out
 
     def raft_frames(self) -> tuple[int, int]:
-        """Frames whose adjacent pairs this rank needs: its flow chunks + the 5-flow completion halos."""
+        """Frames whose adjacent pairs this rank's flow completion reads (its flow chunks + the 5-flow halos; the
+        halo flows arrive through exchange x0, RAFT itself runs on the owned pairs only)."""
         ch = self.flow_chunks()
         if not ch:
             return (0, 0)
@@ -154,15 +157,41 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
     T = plan.T
     F0, F1 = plan.frames
     frames_all = backend.to_frames(frames_u8)
-    # ---- A: RAFT (+halo) and flow completion of the owned chunks ------------------------------------
-    ra, rb = plan.raft_frames()
+    # ---- A: RAFT on the owned pairs, seam exchange of the raw flows, flow completion of the owned chunks --------
+    # (RAFT is per-pair independent -- tests/test_raft.py -- so a neighbour's flows are the ones this rank would
+    #  have computed itself: the 5-flow completion halos are exchanged instead of recomputed)
+    fa, fb = plan.flows
+    HAL = 5
+    dev = frames_all.device
+    zero_flows = torch.zeros((2, 0) + tuple(frames_all.shape[1:3]) + (2,), device=dev)
+    raw = backend.raft(frames_all[fa:fb + 1]) if fb > fa else zero_flows
+    k = min(HAL, fb - fa)
+    # x0: the first / last (up to) 5 raw flows of every rank
+    g_seam = yield torch.cat([_pad_first(raw[:, :k].transpose(0, 1), HAL),
+                              _pad_first(raw[:, fb - fa - k:].transpose(0, 1), HAL)], 0)
+
+    def raw_flow(g: int) -> torch.Tensor:        # global flow index -> [2,H,W,2]
+        if fa <= g < fb:
+            return raw[:, g - fa]
+        for r, (a, b) in enumerate(plan.flow_ranges):
+            if a <= g < b:
+                kr = min(HAL, b - a)
+                if g - a < kr:
+                    return g_seam[r][g - a]
+                if b - g <= kr:
+                    return g_seam[r][HAL + (g - (b - kr))]
+                raise AssertionError(f"flow {g} is not inside a seam of rank {r}")
+        raise IndexError(g)
+
     max_flows = max(b - a for a, b in plan.flow_ranges)
     own = []
-    if rb - ra >= 2:
-        gt = backend.raft(frames_all[ra:rb])
-        for f, e_own, s, e in plan.flow_chunks():
-            sub = backend.complete(gt[:, s - ra:e - ra], flow_masks_u8[s:e + 1])
-            own.append(sub[:, f - s:e_own - s])
+    for f, e_own, s, e in plan.flow_chunks():
+        left = [raw_flow(g) for g in range(s, min(e, fa))]
+        right = [raw_flow(g) for g in range(max(s, fb), e)]
+        mid = raw[:, max(s, fa) - fa:min(e, fb) - fa]
+        gt = torch.cat(([torch.stack(left, 1)] if left else []) + [mid] + ([torch.stack(right, 1)] if right else []), 1)
+        sub = backend.complete(gt, flow_masks_u8[s:e + 1])
+        own.append(sub[:, f - s:e_own - s])
     flow_shape = (2, 0) + tuple(frames_all.shape[1:3]) + (2,)
     own_flows = torch.cat(own, 1) if own else torch.zeros(flow_shape, device=frames_all.device)
     # x1: completed flows of every rank
