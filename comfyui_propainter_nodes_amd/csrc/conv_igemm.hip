@@ -219,10 +219,15 @@ struct TileGeom {
   static constexpr int RPP = 256 / PPR;  // tile rows filled per 256-thread pass
   // DMA: tiles staged with global_load_lds (no VGPR round trip, no ds_write) when every wave-instruction of the
   // staging pass covers whole tile rows of both tiles; otherwise global -> VGPR -> LDS.
-  static constexpr bool DMA = (BP % RPP == 0) && pad_ok(BC, RPP);
+  // A pixel tile shorter than one pass (32-pixel tiles) is copied by the first BP*PPR/64 waves' worth of lanes; the
+  // other waves repeat the same copies (identical data, same LDS slots) so that every wave counts the same vmcnt.
+  static constexpr bool XPARTIAL = (BP < RPP) && (RPP % BP == 0) && (BP * PPR >= 64);
+  static constexpr bool DMA = ((BP % RPP == 0) || XPARTIAL) && pad_ok(BC, RPP);
   static constexpr int BCP = DMA ? (BC + RPP - 1) / RPP * RPP : BC;  // weight-tile rows allocated in LDS
-  // 3-stage ring (two chunks in flight across the single barrier per chunk) when one stage is <= 16 KiB
-  static constexpr int NST = (DMA && (sizeof(T) == 2 || BK == 16)) ? 3 : 2;
+  // Ring of NST stages, NST-1 chunks in flight across the single barrier per chunk: 3 when one stage is <= 16 KiB;
+  // 6 for the f16 32-pixel tiles (launched when the grid is about one work-group per CU: nothing else hides the
+  // global->LDS latency of the long serial K loop of the recurrences' convolutions)
+  static constexpr int NST = !DMA ? 2 : (sizeof(T) == 2 && BP == 32) ? 6 : (sizeof(T) == 2 || BK == 16) ? 3 : 2;
 };
 
 template <typename T, typename OT, int WC, int WP, int TC, int TP, bool M32, int KC>
@@ -269,13 +274,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   const int row0 = tid / PPR;
   // LDS slot (r, pc) holds global piece pc ^ swz(r); RPP is a multiple of 16, so swz(r) = swz(row0) for every pass
   const int pcs = pc ^ ((row0 >> SWZ_SHIFT) & SWZ_MASK);
+  // pixel-tile row of this thread's piece (partial pass: the waves beyond the tile wrap around; BP is a multiple of
+  // 16, so the swizzle of the wrapped row is the same)
+  constexpr int XWAVES = G::XPARTIAL ? BP * PPR / 64 : 4;
+  const int wave_x = G::XPARTIAL ? wave % XWAVES : wave;
+  const int row0x = G::XPARTIAL ? row0 % BP : row0;
 
   // ---- per-thread pixel rows of the X tile --------------------------------------------
   int py0[XPASS], px0[XPASS];
   int64_t pn[XPASS], prow[XPASS];
 #pragma unroll
   for (int i = 0; i < XPASS; ++i) {
-    const int r = row0 + i * RPP;
+    const int r = row0x + i * RPP;
     const int64_t m = p_base + r;
     const int64_t mm = (r < BP && m < p.M) ? m : p.M - 1;  // rows past M: clamped, results never stored
     const int wo = (int)(mm % p.Wo);
@@ -408,7 +418,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         pix = prow[i] + tapoff;
       }
       const void* src = ok ? static_cast<const void*>(sbase + pix * ldc + c0) : static_cast<const void*>(pp_zero16);
-      glds16(src, xt + (i * 256 + wave * 64) * EPP);
+      glds16(src, xt + (i * 256 + wave_x * 64) * EPP);
     }
     const int woff = it_woff();
 #pragma unroll
@@ -525,17 +535,28 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 
   };
 
-  if constexpr (NST == 3) {
-    // prologue issued chunk 0 (and waited for it); put chunk 1 in flight as well
-    if (nstages > 1) dma_stage(1);
+  if constexpr (NST >= 3) {
+    static_assert((NST - 2) * NLOADS <= 63, "vmcnt is a 6-bit counter");
+    // prologue issued chunk 0 (and waited for it); put chunks 1 .. NST-2 in flight as well
+#pragma unroll
+    for (int j = 1; j < NST - 1; ++j)
+      if (j < nstages) dma_stage(j);
+    // this wave's copies of chunk qs have landed when at most min(NST-2, chunks after qs) later chunks are pending
+    auto wait_landed = [&](int after) PP_INLINE_LAMBDA {
+      static_for<NST - 1>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+        if (after == c || (c == NST - 2 && after > c)) pp_wait_vmcnt<c * NLOADS>();
+      });
+    };
+    int st = 0;  // qs % NST
     for (int qs = 0; qs < nstages; ++qs) {
       if (qs > 0) {
-        // chunk qs landed (this wave's part): at most the NLOADS copies of chunk qs+1 may still be in flight
-        if (qs + 1 < nstages) pp_wait_vmcnt<NLOADS>(); else pp_wait_vmcnt<0>();
-        pp_barrier();  // every wave's part of chunk qs is visible; everyone is done reading stage (qs-1)%3
+        wait_landed(nstages - 1 - qs);
+        pp_barrier();  // every wave's part of chunk qs is visible; everyone is done reading stage (qs-1) % NST
       }
-      if (qs + 2 < nstages) dma_stage((qs + 2) % 3);
-      compute(qs % 3);
+      if (qs + NST - 1 < nstages) dma_stage(st == 0 ? NST - 1 : st - 1);
+      compute(st);
+      st = st + 1 == NST ? 0 : st + 1;
     }
   } else {
     for (int qs = 0; qs < nstages; ++qs) {
