@@ -203,6 +203,16 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
   }
 }
 
+// one 16-byte f16 MFMA fragment from LDS (PP_ABLATE & 16: a register constant instead)
+__device__ __forceinline__ h8 lds_frag(const void* ptr) {
+#if PP_ABLATE & 16
+  const half_t v = (half_t)(float)(reinterpret_cast<uintptr_t>(ptr) & 1);
+  return h8{v, v, v, v, v, v, v, v};
+#else
+  return *reinterpret_cast<const h8*>(ptr);
+#endif
+}
+
 // Staging geometry shared by the kernel and its launcher.
 template <typename T, int BC, int BP>
 struct TileGeom {
@@ -418,11 +428,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         pix = prow[i] + tapoff;
       }
       const void* src = ok ? static_cast<const void*>(sbase + pix * ldc + c0) : static_cast<const void*>(pp_zero16);
-      glds16(src, xt + (i * 256 + wave_x * 64) * EPP);
+      if constexpr (!(PP_ABLATE & 2)) glds16(src, xt + (i * 256 + wave_x * 64) * EPP);
     }
     const int woff = it_woff();
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * EPP);
+    for (int i = 0; i < WPASS; ++i)
+      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * EPP);
     advance();
   };
   auto dma_stage = [&](int buf) PP_INLINE_LAMBDA { static_for<KC>([&](auto kci) { dma_chunk(buf, kci); }); };
@@ -485,9 +496,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         const T* ws = wt + (wc * TC * 16 + frow) * LDK;
         h8 af[TC], bf[TP];
 #pragma unroll
-        for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(ws + a * 16 * LDK + (fgrp ^ fswz) * 8);
+        for (int a = 0; a < TC; ++a) af[a] = lds_frag(ws + a * 16 * LDK + (fgrp ^ fswz) * 8);
 #pragma unroll
-        for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const h8*>(xs + b * 16 * LDK + (fgrp ^ fswz) * 8);
+        for (int b = 0; b < TP; ++b) bf[b] = lds_frag(xs + b * 16 * LDK + (fgrp ^ fswz) * 8);
 #pragma unroll
         for (int a = 0; a < TC; ++a)
 #pragma unroll
@@ -727,7 +738,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
     unsigned char* wt = smem + 2 * XSTAGE + wbuf * WSTAGE;
     const int woff = it_woff();
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * 16);
+    for (int i = 0; i < WPASS; ++i)
+      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * 16);
     const int c0 = it_rem * 32 + xj * 8;
     const int dy = it_ky * p.dh, dx = it_kx * p.dw;
     const int64_t tapoff = (int64_t)dy * p.W + dx;
@@ -749,8 +761,12 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
       // segment channel counts are multiples of 4: each half octet is either fully valid or padding
       const bool ok0 = ok && (c0 < it_C), ok1 = ok && (c0 + 4 < it_C);
       const float* src = ok0 ? cbase + pix * it_ldc : it_base;
-      gload16_hidden(xreg[P][i][0], src);
-      gload16_hidden(xreg[P][i][1], src + (ok1 ? 4 : 0));
+      if constexpr (!(PP_ABLATE & 2)) {
+        gload16_hidden(xreg[P][i][0], src);
+        gload16_hidden(xreg[P][i][1], src + (ok1 ? 4 : 0));
+      } else {
+        asm volatile("" : "=v"(xreg[P][i][0]), "=v"(xreg[P][i][1]) : "v"(src), "v"(ok1));
+      }
       okbits |= (ok0 ? 1 : 0) << (2 * i) | (ok1 ? 2 : 0) << (2 * i);
     }
     xok[P] = okbits;
@@ -774,11 +790,19 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
-        const h2 hh = cvt_pkrtz_f16(c0, c1);
-        h[e] = hh[0];
-        h[e + 1] = hh[1];
-        l[e] = (half_t)((c0 - (float)hh[0]) * LSCALE);
-        l[e + 1] = (half_t)((c1 - (float)hh[1]) * LSCALE);
+        if constexpr (!(PP_ABLATE & 8)) {
+          const h2 hh = cvt_pkrtz_f16(c0, c1);
+          h[e] = hh[0];
+          h[e + 1] = hh[1];
+          l[e] = (half_t)((c0 - (float)hh[0]) * LSCALE);
+          l[e + 1] = (half_t)((c1 - (float)hh[1]) * LSCALE);
+        } else {  // no arithmetic: the raw bit patterns
+          const h2 r0 = __builtin_bit_cast(h2, c0), r1 = __builtin_bit_cast(h2, c1);
+          h[e] = r0[0];
+          h[e + 1] = r0[1];
+          l[e] = r1[0];
+          l[e + 1] = r1[1];
+        }
       }
       unsigned char* rowp = xs + (xrow0 + i * 64) * ROWB;
       *reinterpret_cast<h8*>(rowp + xoff_h) = h;
@@ -806,13 +830,13 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
     h8 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
     for (int a = 0; a < TC; ++a) {
-      ah[a] = *reinterpret_cast<const h8*>(ws + a * 16 * ROWB + roff_h);
-      al[a] = *reinterpret_cast<const h8*>(ws + a * 16 * ROWB + roff_l);
+      ah[a] = lds_frag(ws + a * 16 * ROWB + roff_h);
+      al[a] = lds_frag(ws + a * 16 * ROWB + roff_l);
     }
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
-      bh[b] = *reinterpret_cast<const h8*>(xs + b * 16 * ROWB + roff_h);
-      bl[b] = *reinterpret_cast<const h8*>(xs + b * 16 * ROWB + roff_l);
+      bh[b] = lds_frag(xs + b * 16 * ROWB + roff_h);
+      bl[b] = lds_frag(xs + b * 16 * ROWB + roff_l);
     }
     // three sweeps over the tile grid: two MFMAs on one accumulator are always TC*TP instructions apart
 #pragma unroll
