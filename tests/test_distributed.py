@@ -83,6 +83,28 @@ def test_sharded_equals_single_rank_over_gloo(tmp_path, world, T, nl, rs, sv):
     assert ref.float().std() > 10  # the toy clip is not degenerate
 
 
+@pytest.mark.parametrize("world,T,nl,rs,sv", [
+    (4, 13, 4, 2, 3),    # 3-flow chunks: a 5-flow completion halo spans two neighbouring ranks (seam exchange x0)
+    (5, 11, 4, 2, 2),    # 2-flow chunks, more ranks than a halo is long
+    (8, 17, 6, 3, 100),  # more ranks than chunks: 7 idle ranks take part in every exchange
+    (3, 2, 2, 1, 1),     # a single flow
+    (2, 23, 10, 5, 7),   # ragged last chunk
+])
+def test_sharded_equals_single_rank_edge_cases(world, T, nl, rs, sv):
+    """In-process virtual ranks (the same generator the RCCL runner drives) on shard plans with short chunks, idle
+    ranks and ragged tails: every rank must return the single-rank result bit for bit."""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).parent))
+    from toy_backend import ToyBackend
+
+    frames, fm, md = _toy_inputs(T)
+    ref = D.run_simulated(lambda r: ToyBackend(), 1, _cfg(T, nl, rs, sv), frames, fm, md)[0]
+    sim = D.run_simulated(lambda r: ToyBackend(), world, _cfg(T, nl, rs, sv), frames, fm, md)
+    for r, got in enumerate(sim):
+        assert got.shape == ref.shape and torch.equal(got, ref), f"virtual rank {r} differs"
+
+
 @pytest.mark.gpu
 def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib):
     from comfyui_propainter_nodes_amd import weights
