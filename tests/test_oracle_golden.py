@@ -33,3 +33,20 @@ def test_oracle_reproduces_reference_fixture(case):
     assert torch.allclose(pi, torch.from_numpy(g["pred_imgs"]).float(), atol=2e-3)
     out = np.stack(comp, 0)
     assert np.abs(out.astype(np.int32) - g["out_image"].astype(np.int32)).max() <= 1
+
+
+def test_oracle_with_empty_masks_returns_the_input_frames():
+    """Size-independent property of the path (propainter_inference.py:331-340: comp = pred*mask + frame*(1-mask)):
+    with nothing to inpaint the composed uint8 frames are the input frames, whatever the networks predict."""
+    from comfyui_propainter_nodes_amd import synth
+
+    T, H, W = 3, 64, 64
+    image, _ = synth.synthetic_clip(T, H, W, 7)
+    frames_u8 = (image.numpy() * 255).clip(0, 255).astype(np.uint8)
+    frames = (torch.from_numpy(frames_u8).float().div(255) * 2 - 1).permute(0, 3, 1, 2)[None]
+    zeros = torch.zeros(1, T, 1, H, W)
+    sds = weights.synth_state_dicts(0)
+    torch.set_num_threads(8)
+    comp = OP.run(sds, frames, zeros, zeros, [f for f in frames_u8], raft_iter=2, neighbor_length=2, ref_stride=2,
+                  subvideo_length=80)
+    assert np.array_equal(np.stack(comp, 0), frames_u8)
