@@ -24,6 +24,7 @@
 #include "pp_host.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 #include <utility>
@@ -214,7 +215,7 @@ __device__ __forceinline__ h8 lds_frag(const void* ptr) {
 }
 
 // Staging geometry shared by the kernel and its launcher.
-template <typename T, int BC, int BP>
+template <typename T, int BC, int BP, int NT = 256>
 struct TileGeom {
   static constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
   // K chunk staged per pipeline step: 32 channels of one (tap, segment); f32 tiles whose rows fill whole
@@ -226,7 +227,7 @@ struct TileGeom {
   }
   static constexpr int BK = (sizeof(T) == 4 && BP % 64 == 0 && pad_ok(BC, 64)) ? 16 : 32;
   static constexpr int PPR = BK / EPP;   // 16-byte pieces per tile row
-  static constexpr int RPP = 256 / PPR;  // tile rows filled per 256-thread pass
+  static constexpr int RPP = NT / PPR;   // tile rows filled per pass of the NT threads of the work-group
   // DMA: tiles staged with global_load_lds (no VGPR round trip, no ds_write) when every wave-instruction of the
   // staging pass covers whole tile rows of both tiles; otherwise global -> VGPR -> LDS.
   // A pixel tile shorter than one pass (32-pixel tiles) is copied by the first BP*PPR/64 waves' worth of lanes; the
@@ -241,8 +242,9 @@ struct TileGeom {
 };
 
 template <typename T, typename OT, int WC, int WP, int TC, int TP, bool M32, int KC>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
-  typedef TileGeom<T, WC * TC * 16, WP * TP * 16> G;
+__global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(const ConvK p) {
+  constexpr int NT = WC * WP * 64;  // threads per work-group (4 waves; 8 for the 256-channel tiles)
+  typedef TileGeom<T, WC * TC * 16, WP * TP * 16, NT> G;
   constexpr int BK = G::BK;
   constexpr int CM = 32 / BK;    // pipeline steps per 32-channel chunk of the packed weights
   constexpr int EPP = G::EPP;
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
   const int pcs = pc ^ ((row0 >> SWZ_SHIFT) & SWZ_MASK);
   // pixel-tile row of this thread's piece (partial pass: the waves beyond the tile wrap around; BP is a multiple of
   // 16, so the swizzle of the wrapped row is the same)
-  constexpr int XWAVES = G::XPARTIAL ? BP * PPR / 64 : 4;
+  constexpr int XWAVES = G::XPARTIAL ? BP * PPR / 64 : NT / 64;
   const int wave_x = G::XPARTIAL ? wave % XWAVES : wave;
   const int row0x = G::XPARTIAL ? row0 % BP : row0;
 
@@ -428,12 +430,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
         pix = prow[i] + tapoff;
       }
       const void* src = ok ? static_cast<const void*>(sbase + pix * ldc + c0) : static_cast<const void*>(pp_zero16);
-      if constexpr (!(PP_ABLATE & 2)) glds16(src, xt + (i * 256 + wave_x * 64) * EPP);
+      if constexpr (!(PP_ABLATE & 2)) glds16(src, xt + (i * NT + wave_x * 64) * EPP);
     }
     const int woff = it_woff();
 #pragma unroll
     for (int i = 0; i < WPASS; ++i)
-      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * EPP);
+      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * EPP);
     advance();
   };
   auto dma_stage = [&](int buf) PP_INLINE_LAMBDA { static_for<KC>([&](auto kci) { dma_chunk(buf, kci); }); };
@@ -633,13 +635,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvK p) {
 // order as the f32 packing) and copied by global_load_lds; pixels are loaded as f32 (8 channels per thread), split
 // in registers and written with one ds_write_b128 per plane.  One barrier per chunk, two chunks in flight.
 template <typename OT, int WC, int WP, int TC, int TP>
-__global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
+__global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK p) {
+  constexpr int NT = WC * WP * 64;          // threads per work-group (4 waves; 8 for the 256-channel tile)
+  constexpr int XROWS = NT / 4, WROWS = NT / 8;  // tile rows covered by one pass of the work-group
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
-  constexpr int BCP = (BC + 31) / 32 * 32;  // weight rows staged (rows past BC are never read)
+  constexpr int BCP = (BC + WROWS - 1) / WROWS * WROWS;  // weight rows staged (rows past BC are never read)
   constexpr int ROWB = 128;                 // bytes per tile row
-  constexpr int XPASS = (BP + 63) / 64;     // pixel passes: 4 threads per row (8 channels each), 64 rows per pass
-  constexpr int WPASS = BCP / 32;           // weight passes: 8 threads per row (16 bytes each), 32 rows per pass
+  constexpr int XPASS = (BP + XROWS - 1) / XROWS;  // pixel passes: 4 threads per row (8 channels each)
+  constexpr int WPASS = BCP / WROWS;        // weight passes: 8 threads per row (16 bytes each)
   // LDS: 2 pixel stages + 3 weight stages.  Pixels of chunk q+2 are in flight to registers and weights of chunk
   // q+2 in flight to LDS while chunk q is multiplied: two chunks of latency cover per work-group.
   constexpr int XSTAGE = BP * ROWB, WSTAGE = BCP * ROWB;
@@ -679,7 +683,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   int pyx[XPASS];
 #pragma unroll
   for (int i = 0; i < XPASS; ++i) {
-    const int r = xrow0 + i * 64;
+    const int r = xrow0 + i * XROWS;
     const int64_t m = p_base + r;
     const int64_t mm = (r < BP && m < p.M) ? m : p.M - 1;  // rows past M: clamped, results never stored
     const int wo = (int)(mm % p.Wo);
@@ -694,7 +698,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
   const float* wrow[WPASS];
 #pragma unroll
   for (int i = 0; i < WPASS; ++i) {
-    const int co = c_base + wrow0 + i * 32;
+    const int co = c_base + wrow0 + i * WROWS;
     wrow[i] = wbase + (int64_t)(co < p.Cout ? co : p.Cout - 1) * p.Kp + pcs * 4;
   }
 
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
     const int woff = it_woff();
 #pragma unroll
     for (int i = 0; i < WPASS; ++i)
-      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * 256 + wave * 64) * 16);
+      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
     const int c0 = it_rem * 32 + xj * 8;
     const int dy = it_ky * p.dh, dx = it_kx * p.dw;
     const int64_t tapoff = (int64_t)dy * p.W + dx;
@@ -782,7 +786,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
     wait_vmcnt_hidden<decltype(later)::value>();
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
-      if (BP % 64 != 0 && xrow0 + i * 64 >= BP) continue;
+      if (BP % XROWS != 0 && xrow0 + i * XROWS >= BP) continue;
       f4 v[2] = {xreg[P][i][0], xreg[P][i][1]};
       if (!((xok[P] >> (2 * i)) & 1)) v[0] = f4{0.f, 0.f, 0.f, 0.f};
       if (!((xok[P] >> (2 * i)) & 2)) v[1] = f4{0.f, 0.f, 0.f, 0.f};
@@ -804,7 +808,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvK p) {
           l[e + 1] = r1[1];
         }
       }
-      unsigned char* rowp = xs + (xrow0 + i * 64) * ROWB;
+      unsigned char* rowp = xs + (xrow0 + i * XROWS) * ROWB;
       *reinterpret_cast<h8*>(rowp + xoff_h) = h;
       *reinterpret_cast<h8*>(rowp + xoff_l) = l;
     }
@@ -906,12 +910,13 @@ template <typename OT, int WC, int WP, int TC, int TP>
 static int launch_split_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
-  constexpr int BCP = (BC + 31) / 32 * 32;
+  constexpr int NT = WC * WP * 64;
+  constexpr int BCP = (BC + NT / 8 - 1) / (NT / 8) * (NT / 8);
   const size_t smem = (size_t)(2 * BP + 3 * BCP) * 128;
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_split_kernel<OT, WC, WP, TC, TP>), smem), true);
   (void)lds_ok;
-  PP_LAUNCH((conv_split_kernel<OT, WC, WP, TC, TP>), grid, dim3(256), smem, stream, k);
+  PP_LAUNCH((conv_split_kernel<OT, WC, WP, TC, TP>), grid, dim3(NT), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }
 
@@ -924,12 +929,13 @@ static int launch_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int KC = 1;
   constexpr int BC = WC * TC * 16;
   constexpr int BP = WP * TP * 16;
-  typedef TileGeom<T, BC, BP> G;
+  constexpr int NT = WC * WP * 64;
+  typedef TileGeom<T, BC, BP, NT> G;
   const size_t smem = (size_t)G::NST * KC * (G::BCP + BP) * G::BK * sizeof(T);
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem), true);
   (void)lds_ok;  // once per instantiation, not per launch
-  PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), grid, dim3(256), smem, stream, k);
+  PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), grid, dim3(NT), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }
 
@@ -952,11 +958,18 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
   // Small problems (the per-step convolutions of the two recurrences: M = 2*45*80 or 90*160 pixels) would
   // fill only a fraction of the 256 CUs with 128-pixel tiles: switch to 32-pixel tiles (4x the work-groups).
   const int64_t blocks128 = ((k.M + 127) / 128) * ((k.Cout + 127) / 128) * Z;
-  static const int forced = [] {  // PP_CONV_TILE=large|small pins the choice (tests cover both tile families)
+  // PP_CONV_TILE=large|small pins the choice (tests cover both tile families).  Experiment (not a default yet):
+  // PP_CONV_TILE=xl uses 8-wave 256-channel x 128-pixel tiles for Cout % 256 == 0 when the problem is large
+  // (half the pixel-tile gather per flop); "xlforce" does so regardless of the problem size (tests).
+  static const int forced = [] {
     const char* e = getenv("PP_CONV_TILE");
-    return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0));
+    if (!e) return 0;
+    if (e[0] == 'x') return strcmp(e, "xlforce") == 0 ? 4 : 3;
+    return e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
   }();
-  const bool small = forced == 2 || (forced == 0 && blocks128 < 224);
+  const bool small = forced == 2 || ((forced == 0 || forced == 3) && blocks128 < 224);
+  if (forced >= 3 && k.Cout % 256 == 0 && (forced == 4 || blocks128 >= 1024))
+    return F::template run<4, 2, 4, 4>(stream, k, Z);                                // 256 x 128, 8 waves
   if (k.Cout > 64) {
     if (small) return F::template run<4, 1, 2, 2>(stream, k, Z);                     // 128 x  32
     // 96-wide tiles when they waste clearly fewer output channels than 128-wide ones (Cout 192, 576, ...)

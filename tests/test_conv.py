@@ -24,6 +24,10 @@ CASES = [
     (torch.float16, 1, 20, 23, [16], 40, 7, 3, 3, 1, 1, None),
     (torch.float32, 1, 11, 12, [8], 24, 7, 1, 3, 1, 1, "relu"),
     ("f32x2", 1, 11, 12, [8], 24, 7, 1, 3, 1, 1, "relu"),
+    # Cout % 256 == 0: the 8-wave 256 x 128 tiles under PP_CONV_TILE=xlforce
+    (torch.float16, 1, 13, 12, [32, 8], 256, 3, 1, 1, 1, 1, "leaky"),
+    (torch.float32, 1, 9, 10, [8], 256, 3, 1, 1, 1, 1, None),
+    ("f32x2", 1, 13, 12, [16, 8], 256, (1, 5), 1, (0, 2), 1, 1, "tanh"),
     # PP_F32X2: f32 tensors on the f16 matrix pipe (two-term operand split), every tile family
     ("f32x2", 1, 9, 11, [8], 20, 3, 1, 1, 1, 1, None),
     ("f32x2", 2, 9, 11, [8, 36], 70, 3, 2, 1, 1, 1, "leaky"),
@@ -44,8 +48,10 @@ def _ref_input(x, segC, groups):
     return torch.cat(parts, 3).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("be", ["emu", pytest.param("hip", marks=pytest.mark.gpu)])
-@pytest.mark.parametrize("tile", ["large", "small"])
+# ("xlforce" = the experimental 8-wave 256-channel tiles: emulator only until they have been measured on the MI355X)
+@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"),
+                                     pytest.param("hip", "large", marks=pytest.mark.gpu),
+                                     pytest.param("hip", "small", marks=pytest.mark.gpu)])
 def test_conv2d_matches_torch(be, tile):
     """Every case on both tile families (128-pixel tiles / 32-pixel tiles for small problems).  The tile
     choice is read once per process (PP_CONV_TILE), so each family runs in a fresh interpreter."""
