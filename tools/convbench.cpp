@@ -41,6 +41,7 @@ static const std::vector<Shape> SHAPES = {
     {"raft_convc2_f32x2", PP_F32X2, 158, 45, 80, {256}, 192, 3, 3, 1, 1},
     {"raft_fh1_f32x2", PP_F32X2, 158, 45, 80, {128}, 256, 3, 3, 1, 1},
     {"enc_3x3_256_384_f16", PP_F16, 16, 90, 160, {256}, 384, 3, 3, 1, 1},
+    {"f16_3x3_256_512", PP_F16, 16, 90, 160, {256}, 512, 3, 3, 1, 1},
     {"dcn_offset_f16", PP_F16, 16, 90, 160, {128, 128, 8}, 128, 3, 3, 1, 1},
     {"fc1_f16", PP_F16, 1, 1, 29160, {512}, 1960, 1, 1, 0, 0},
     {"qkv_f16", PP_F16, 1, 1, 27540, {512}, 1536, 1, 1, 0, 0},
