@@ -959,7 +959,7 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
   // fill only a fraction of the 256 CUs with 128-pixel tiles: switch to 32-pixel tiles (4x the work-groups).
   const int64_t blocks128 = ((k.M + 127) / 128) * ((k.Cout + 127) / 128) * Z;
   // PP_CONV_TILE=large|small pins the choice (tests cover both tile families).  Experiment (not a default yet):
-  // PP_CONV_TILE=xl uses 8-wave 256-channel x 128-pixel tiles for Cout % 256 == 0 when the problem is large
+  // PP_CONV_TILE=xl uses 8-wave 256-channel x 128-pixel tiles when the problem is large
   // (half the pixel-tile gather per flop); "xlforce" does so regardless of the problem size (tests).
   static const int forced = [] {
     const char* e = getenv("PP_CONV_TILE");
@@ -968,7 +968,9 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
     return e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
   }();
   const bool small = forced == 2 || ((forced == 0 || forced == 3) && blocks128 < 224);
-  if (forced >= 3 && k.Cout % 256 == 0 && (forced == 4 || blocks128 >= 1024))
+  // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would)
+  const bool fits256 = (k.Cout + 255) / 256 * 256 == (k.Cout + 127) / 128 * 128;
+  if (forced >= 3 && fits256 && (forced == 4 || blocks128 >= 1024))
     return F::template run<4, 2, 4, 4>(stream, k, Z);                                // 256 x 128, 8 waves
   if (k.Cout > 64) {
     if (small) return F::template run<4, 1, 2, 2>(stream, k, Z);                     // 128 x  32

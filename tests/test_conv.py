@@ -28,6 +28,8 @@ CASES = [
     (torch.float16, 1, 13, 12, [32, 8], 256, 3, 1, 1, 1, 1, "leaky"),
     (torch.float32, 1, 9, 10, [8], 256, 3, 1, 1, 1, 1, None),
     ("f32x2", 1, 13, 12, [16, 8], 256, (1, 5), 1, (0, 2), 1, 1, "tanh"),
+    (torch.float16, 1, 6, 7, [32], 472, 1, 1, 0, 1, 1, None),      # partial last 256-channel tile
+    ("f32x2", 1, 6, 7, [16], 472, 3, 1, 1, 1, 1, "relu"),
     # PP_F32X2: f32 tensors on the f16 matrix pipe (two-term operand split), every tile family
     ("f32x2", 1, 9, 11, [8], 20, 3, 1, 1, 1, 1, None),
     ("f32x2", 2, 9, 11, [8, 36], 70, 3, 2, 1, 1, 1, "leaky"),
