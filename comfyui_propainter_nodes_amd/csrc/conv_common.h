@@ -1,0 +1,241 @@
+// conv_common.h -- pieces shared by the convolution translation units (conv_igemm.hip, conv_split.hip):
+// kernel-argument block, fused epilogue, compile-time loops, tile-family dispatch.
+#pragma once
+#include "pp_device.h"
+#include "pp_host.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+
+namespace pp {
+
+
+// helper lambdas of the kernels must never become real calls (a call makes the kernel-argument struct and the
+// register arrays addressable: both would move to scratch memory)
+#define PP_INLINE_LAMBDA __attribute__((always_inline))
+
+struct ConvK {
+  const void* in_ptr[PP_MAX_SEG];
+  int in_C[PP_MAX_SEG];
+  int in_ldc[PP_MAX_SEG];
+  int64_t in_zoff[PP_MAX_SEG];
+  int seg_chunks[PP_MAX_SEG];
+  int nseg;
+  int N, H, W, Ho, Wo;
+  int kh, kw, sh, sw, ph, pw, dh, dw;
+  int pad_mode;
+  const void* weight;
+  int64_t w_zoff;
+  int Kp;
+  const float* bias;
+  int64_t bias_zoff;
+  int Cout;
+  int64_t M;
+  void* out;
+  int out_ldc;
+  int64_t out_zoff;
+  int act, act2, act_split;
+  float act_param, out_scale;
+  int epi;
+  const void* aux1;
+  int aux1_ldc;
+  int64_t aux1_zoff;
+  const void* aux2;
+  int aux2_ldc;
+  int64_t aux2_zoff;
+  int chunks_per_tap;
+  int nchunks;
+  const void* pre_add;
+  int pre_add_ldc;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float param) {
+  switch (act) {
+    case PP_ACT_RELU: return v > 0.f ? v : 0.f;
+    case PP_ACT_LEAKY: return v > 0.f ? v : v * param;
+    case PP_ACT_SIGMOID: return sigmoidf_(v);
+    case PP_ACT_TANH: return tanhf_(v);
+    case PP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    default: return v;
+  }
+}
+
+template <typename T>
+struct Frag;
+template <>
+struct Frag<half_t> {
+  typedef h8 piece;  // 16 bytes
+};
+template <>
+struct Frag<float> {
+  typedef f4 piece;
+};
+
+// compile-time loop: the body receives std::integral_constant<int, I>, so every index derived from it
+// is a constant expression (register arrays indexed with it can never fall back to scratch memory)
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <typename OT>
+struct EpiCtx {
+  const float* bias;
+  OT* out;
+  const OT* aux1;
+  const OT* aux2;
+  const OT* pre;
+};
+
+// 4 consecutive channels of one pixel row as floats: one 8/16-byte load when `vec`, else guarded scalars
+template <typename ET>
+__device__ __forceinline__ f4 load_quad(const ET* src, bool vec, int nvalid) {
+  f4 r = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    if constexpr (sizeof(ET) == 2) {
+      const h4 t = *reinterpret_cast<const h4*>(src);
+      r = f4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    } else {
+      r = *reinterpret_cast<const f4*>(src);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nvalid) r[i] = to_f32(src[i]);
+  }
+  return r;
+}
+
+template <typename ET>
+__device__ __forceinline__ bool quad_aligned(const ET* ptr, int64_t ldc) {
+  return ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(ptr) & (4 * sizeof(ET) - 1)) == 0);
+}
+
+// bias + activation(s) + scale + fused epilogue op + channels-last store of 4 consecutive channels
+template <typename OT>
+__device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, f4 accv, int64_t m, int c) {
+  const int nvalid = p.Cout - c;  // >= 1 (caller checks c < Cout)
+  const bool full = nvalid >= 4;
+  f4 v = accv;
+  if (e.bias) {
+    const f4 b = load_quad(e.bias + c, full && ((c & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0), nvalid);
+    v += b;
+  }
+  if (e.pre) {
+    const OT* src = e.pre + m * p.pre_add_ldc + c;
+    v += load_quad(src, full && quad_aligned(src, p.pre_add_ldc), nvalid);
+  }
+  if (p.act_split > 0 && c + 3 >= p.act_split && c < p.act_split) {
+    // quad straddles the act/act2 boundary (never happens for the shipped nets: split % 4 == 0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (c + r >= p.act_split) {
+        v[r] = apply_act(v[r], p.act2, p.act_param);
+      } else {
+        v[r] = apply_act(v[r], p.act, p.act_param);
+        if (p.out_scale != 0.f) v[r] *= p.out_scale;
+      }
+    }
+  } else if (p.act_split > 0 && c >= p.act_split) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2, p.act_param);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.act_param);
+    if (p.out_scale != 0.f) v *= p.out_scale;
+  }
+  if (p.epi != PP_EPI_NONE) {
+    const OT* s1 = e.aux1 + m * p.aux1_ldc + c;
+    const f4 a1 = load_quad(s1, full && quad_aligned(s1, p.aux1_ldc), nvalid);
+    if (p.epi == PP_EPI_MUL_AUX1) {
+      v *= a1;
+    } else if (p.epi == PP_EPI_ADD_AUX1) {
+      v += a1;
+    } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = v[r] + a1[r];
+        v[r] = s > 0.f ? s : 0.f;
+      }
+    } else if (p.epi == PP_EPI_GRU) {
+      const OT* s2 = e.aux2 + m * p.aux2_ldc + c;
+      const f4 h = load_quad(s2, full && quad_aligned(s2, p.aux2_ldc), nvalid);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (1.f - a1[r]) * h[r] + a1[r] * v[r];
+    }
+  }
+  OT* dst = e.out + m * p.out_ldc + c;
+  if (full && quad_aligned(dst, p.out_ldc)) {
+    if constexpr (sizeof(OT) == 2) {
+      h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<h4*>(dst) = o;
+    } else {
+      *reinterpret_cast<f4*>(dst) = v;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < nvalid) dst[r] = from_f32<OT>(v[r]);
+  }
+}
+
+// one 16-byte f16 MFMA fragment from LDS (PP_ABLATE & 16: a register constant instead)
+__device__ __forceinline__ h8 lds_frag(const void* ptr) {
+#if PP_ABLATE & 16
+  const half_t v = (half_t)(float)(reinterpret_cast<uintptr_t>(ptr) & 1);
+  return h8{v, v, v, v, v, v, v, v};
+#else
+  return *reinterpret_cast<const h8*>(ptr);
+#endif
+}
+
+template <typename F>
+static int launch_by_cout(void* stream, const ConvK& k, int Z) {
+  // Small problems (the per-step convolutions of the two recurrences: M = 2*45*80 or 90*160 pixels) would
+  // fill only a fraction of the 256 CUs with 128-pixel tiles: switch to 32-pixel tiles (4x the work-groups).
+  const int64_t blocks128 = ((k.M + 127) / 128) * ((k.Cout + 127) / 128) * Z;
+  // PP_CONV_TILE=large|small pins the choice (tests cover both tile families).  Experiment (not a default yet):
+  // PP_CONV_TILE=xl uses 8-wave 256-channel x 128-pixel tiles when the problem is large
+  // (half the pixel-tile gather per flop); "xlforce" does so regardless of the problem size (tests).
+  static const int forced = [] {
+    const char* e = getenv("PP_CONV_TILE");
+    if (!e) return 0;
+    if (e[0] == 'x') return strcmp(e, "xlforce") == 0 ? 4 : 3;
+    return e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
+  }();
+  const bool small = forced == 2 || ((forced == 0 || forced == 3) && blocks128 < 224);
+  // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would)
+  const bool fits256 = (k.Cout + 255) / 256 * 256 == (k.Cout + 127) / 128 * 128;
+  if (forced >= 3 && fits256 && (forced == 4 || blocks128 >= 1024))
+    return F::template run<4, 2, 4, 4>(stream, k, Z);                                // 256 x 128, 8 waves
+  if (k.Cout > 64) {
+    if (small) return F::template run<4, 1, 2, 2>(stream, k, Z);                     // 128 x  32
+    // 96-wide tiles when they waste clearly fewer output channels than 128-wide ones (Cout 192, 576, ...)
+    const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
+    const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
+    if (waste96 + 32 <= waste128) {                                                  //  96 x 128
+      // f32 MFMA: one wave column of 96 x 32 so that the wave tile is made of 32x32 MFMA blocks
+      if constexpr (F::m32_wide96) return F::template run<1, 4, 6, 2>(stream, k, Z);
+      else return F::template run<2, 2, 3, 4>(stream, k, Z);
+    }
+    return F::template run<2, 2, 4, 4>(stream, k, Z);                                // 128 x 128
+  }
+  if (k.Cout > 32) {
+    if (small) return F::template run<2, 2, 2, 1>(stream, k, Z);                     //  64 x  32
+    return F::template run<1, 4, 4, 2>(stream, k, Z);                                //  64 x 128
+  }
+  if (k.Cout > 16) return F::template run<1, 4, 2, 2>(stream, k, Z);                 //  32 x 128
+  return F::template run<1, 4, 1, 4>(stream, k, Z);                                  //  16 x 256
+}
+
+// f32 convolution on the f16 matrix pipe (PP_F32X2): conv_split.hip
+int launch_split(void* stream, const ConvK& k, int Z);
+
+}  // namespace pp

@@ -19,200 +19,10 @@
 //   f32 : v_mfma_f32_32x32x2_f32 (wave tile a multiple of 32x32) or v_mfma_f32_16x16x4_f32: exact f32 products.
 //         A lane reads a float4 = 4 consecutive k and feeds element j to MFMA step j for BOTH operands, which
 //         only permutes the summation order.
-//   f32 on the f16 pipe (PP_F32X2): conv_split_kernel below.
-#include "pp_device.h"
-#include "pp_host.h"
-
-#include <stdlib.h>
-#include <string.h>
-
-#include <type_traits>
-#include <utility>
+//   f32 on the f16 pipe (PP_F32X2): conv_split.hip.
+#include "conv_common.h"
 
 namespace pp {
-
-// helper lambdas of the kernels must never become real calls (a call makes the kernel-argument struct and the
-// register arrays addressable: both would move to scratch memory)
-#define PP_INLINE_LAMBDA __attribute__((always_inline))
-
-struct ConvK {
-  const void* in_ptr[PP_MAX_SEG];
-  int in_C[PP_MAX_SEG];
-  int in_ldc[PP_MAX_SEG];
-  int64_t in_zoff[PP_MAX_SEG];
-  int seg_chunks[PP_MAX_SEG];
-  int nseg;
-  int N, H, W, Ho, Wo;
-  int kh, kw, sh, sw, ph, pw, dh, dw;
-  int pad_mode;
-  const void* weight;
-  int64_t w_zoff;
-  int Kp;
-  const float* bias;
-  int64_t bias_zoff;
-  int Cout;
-  int64_t M;
-  void* out;
-  int out_ldc;
-  int64_t out_zoff;
-  int act, act2, act_split;
-  float act_param, out_scale;
-  int epi;
-  const void* aux1;
-  int aux1_ldc;
-  int64_t aux1_zoff;
-  const void* aux2;
-  int aux2_ldc;
-  int64_t aux2_zoff;
-  int chunks_per_tap;
-  int nchunks;
-  const void* pre_add;
-  int pre_add_ldc;
-};
-
-__device__ __forceinline__ float apply_act(float v, int act, float param) {
-  switch (act) {
-    case PP_ACT_RELU: return v > 0.f ? v : 0.f;
-    case PP_ACT_LEAKY: return v > 0.f ? v : v * param;
-    case PP_ACT_SIGMOID: return sigmoidf_(v);
-    case PP_ACT_TANH: return tanhf_(v);
-    case PP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-    default: return v;
-  }
-}
-
-template <typename T>
-struct Frag;
-template <>
-struct Frag<half_t> {
-  typedef h8 piece;  // 16 bytes
-};
-template <>
-struct Frag<float> {
-  typedef f4 piece;
-};
-
-// compile-time loop: the body receives std::integral_constant<int, I>, so every index derived from it
-// is a constant expression (register arrays indexed with it can never fall back to scratch memory)
-template <int N, typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
-template <typename OT>
-struct EpiCtx {
-  const float* bias;
-  OT* out;
-  const OT* aux1;
-  const OT* aux2;
-  const OT* pre;
-};
-
-// 4 consecutive channels of one pixel row as floats: one 8/16-byte load when `vec`, else guarded scalars
-template <typename ET>
-__device__ __forceinline__ f4 load_quad(const ET* src, bool vec, int nvalid) {
-  f4 r = {0.f, 0.f, 0.f, 0.f};
-  if (vec) {
-    if constexpr (sizeof(ET) == 2) {
-      const h4 t = *reinterpret_cast<const h4*>(src);
-      r = f4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-    } else {
-      r = *reinterpret_cast<const f4*>(src);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < nvalid) r[i] = to_f32(src[i]);
-  }
-  return r;
-}
-
-template <typename ET>
-__device__ __forceinline__ bool quad_aligned(const ET* ptr, int64_t ldc) {
-  return ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(ptr) & (4 * sizeof(ET) - 1)) == 0);
-}
-
-// bias + activation(s) + scale + fused epilogue op + channels-last store of 4 consecutive channels
-template <typename OT>
-__device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, f4 accv, int64_t m, int c) {
-  const int nvalid = p.Cout - c;  // >= 1 (caller checks c < Cout)
-  const bool full = nvalid >= 4;
-  f4 v = accv;
-  if (e.bias) {
-    const f4 b = load_quad(e.bias + c, full && ((c & 3) == 0) && ((reinterpret_cast<uintptr_t>(e.bias) & 15) == 0), nvalid);
-    v += b;
-  }
-  if (e.pre) {
-    const OT* src = e.pre + m * p.pre_add_ldc + c;
-    v += load_quad(src, full && quad_aligned(src, p.pre_add_ldc), nvalid);
-  }
-  if (p.act_split > 0 && c + 3 >= p.act_split && c < p.act_split) {
-    // quad straddles the act/act2 boundary (never happens for the shipped nets: split % 4 == 0)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (c + r >= p.act_split) {
-        v[r] = apply_act(v[r], p.act2, p.act_param);
-      } else {
-        v[r] = apply_act(v[r], p.act, p.act_param);
-        if (p.out_scale != 0.f) v[r] *= p.out_scale;
-      }
-    }
-  } else if (p.act_split > 0 && c >= p.act_split) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2, p.act_param);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.act_param);
-    if (p.out_scale != 0.f) v *= p.out_scale;
-  }
-  if (p.epi != PP_EPI_NONE) {
-    const OT* s1 = e.aux1 + m * p.aux1_ldc + c;
-    const f4 a1 = load_quad(s1, full && quad_aligned(s1, p.aux1_ldc), nvalid);
-    if (p.epi == PP_EPI_MUL_AUX1) {
-      v *= a1;
-    } else if (p.epi == PP_EPI_ADD_AUX1) {
-      v += a1;
-    } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s = v[r] + a1[r];
-        v[r] = s > 0.f ? s : 0.f;
-      }
-    } else if (p.epi == PP_EPI_GRU) {
-      const OT* s2 = e.aux2 + m * p.aux2_ldc + c;
-      const f4 h = load_quad(s2, full && quad_aligned(s2, p.aux2_ldc), nvalid);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (1.f - a1[r]) * h[r] + a1[r] * v[r];
-    }
-  }
-  OT* dst = e.out + m * p.out_ldc + c;
-  if (full && quad_aligned(dst, p.out_ldc)) {
-    if constexpr (sizeof(OT) == 2) {
-      h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-      *reinterpret_cast<h4*>(dst) = o;
-    } else {
-      *reinterpret_cast<f4*>(dst) = v;
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (r < nvalid) dst[r] = from_f32<OT>(v[r]);
-  }
-}
-
-// one 16-byte f16 MFMA fragment from LDS (PP_ABLATE & 16: a register constant instead)
-__device__ __forceinline__ h8 lds_frag(const void* ptr) {
-#if PP_ABLATE & 16
-  const half_t v = (half_t)(float)(reinterpret_cast<uintptr_t>(ptr) & 1);
-  return h8{v, v, v, v, v, v, v, v};
-#else
-  return *reinterpret_cast<const h8*>(ptr);
-#endif
-}
 
 // Staging geometry shared by the kernel and its launcher.
 template <typename T, int BC, int BP, int NT = 256>
@@ -621,305 +431,6 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(const ConvK p)
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// f32 convolution on the f16 matrix pipe ("split" mode, dtype PP_F32X2).
-//
-// Every f32 operand value v is represented by two f16 terms  v ~= h + l / 2048,  h = f16(v),
-// l = f16((v - h) * 2048)  (22 significand bits; the 2048 keeps l out of the f16 denormal range).  Then
-//     sum_k w x  ~=  sum_k wh xh  +  ( sum_k wh xl + sum_k wl xh ) / 2048        (the wl xl term is < 2^-22)
-// i.e. three v_mfma_f32_16x16x32_f16 (16x the f32 MFMA rate each) into two fp32 accumulator sets instead of
-// sixteen v_mfma_f32_32x32x2_f32 steps: the same result to fp32 rounding noise, for |v| < 32752.
-//
-// LDS tile row = one 32-channel chunk = 128 bytes = 8 16-byte slots: slots 0-3 the h terms (k 0-31), 4-7 the
-// l terms, slot s stored at s ^ swz(row).  Weights are split on the host (same byte size and chunk
-// order as the f32 packing) and copied by global_load_lds; pixels are loaded as f32 (8 channels per thread), split
-// in registers and written with one ds_write_b128 per plane.  One barrier per chunk, two chunks in flight.
-template <typename OT, int WC, int WP, int TC, int TP>
-__global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK p) {
-  constexpr int NT = WC * WP * 64;          // threads per work-group (4 waves; 8 for the 256-channel tile)
-  constexpr int XROWS = NT / 4, WROWS = NT / 8;  // tile rows covered by one pass of the work-group
-  constexpr int BC = WC * TC * 16;
-  constexpr int BP = WP * TP * 16;
-  constexpr int BCP = (BC + WROWS - 1) / WROWS * WROWS;  // weight rows staged (rows past BC are never read)
-  constexpr int ROWB = 128;                 // bytes per tile row
-  constexpr int XPASS = (BP + XROWS - 1) / XROWS;  // pixel passes: 4 threads per row (8 channels each)
-  constexpr int WPASS = BCP / WROWS;        // weight passes: 8 threads per row (16 bytes each)
-  // LDS: 2 pixel stages + 3 weight stages.  Pixels of chunk q+2 are in flight to registers and weights of chunk
-  // q+2 in flight to LDS while chunk q is multiplied: two chunks of latency cover per work-group.
-  constexpr int XSTAGE = BP * ROWB, WSTAGE = BCP * ROWB;
-  constexpr int NLOADS = WPASS + 2 * XPASS;  // vector-memory instructions per thread per chunk
-  constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
-
-  unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
-
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wc = wave / WP;
-  const int wp = wave % WP;
-  const int z = (int)blockIdx.z;
-  const int64_t p_base = (int64_t)blockIdx.x * BP;
-  const int c_base = (int)blockIdx.y * BC;
-
-  // slot swizzle of tile row r (depends on r mod 16 only): swz(r) = ((r >> 1) & 7) ^ ((r & 1) << 2).
-  //  - fragment reads (16 rows x 4 k-groups per plane): every 16-lane service group of ds_read_b128 hits 16
-  //    distinct 16-byte slots of the 256-byte bank row;
-  //  - pixel writes (ds_write_b128, 8-lane groups = 2 rows x 4 slots of one plane): the odd row's plane lives in
-  //    the other half of the 128-byte row, so the 8 lanes cover 8 distinct slots.
-  auto swz = [](int r) PP_INLINE_LAMBDA { return ((r >> 1) & 7) ^ ((r & 1) << 2); };
-
-  // weights: lane-linear DMA image, LDS slot pc of row wrow0 holds source piece pc ^ swz
-  const int pc = tid & 7;
-  const int wrow0 = tid >> 3;
-  const int pcs = pc ^ swz(wrow0);
-  // pixels: thread = (row xrow0 + 64 i, channel octet xj): h octet -> slot xj ^ swz, l octet -> slot (xj + 4) ^ swz
-  const int xj = tid & 3;
-  const int xrow0 = tid >> 2;
-  const int xoff_h = (xj ^ swz(xrow0)) << 4;
-  const int xoff_l = ((xj + 4) ^ swz(xrow0)) << 4;
-
-  // per pass: pixel index of tap (0,0) and its (y, x), packed to 16 bits each
-  int64_t prow[XPASS];
-  int pyx[XPASS];
-#pragma unroll
-  for (int i = 0; i < XPASS; ++i) {
-    const int r = xrow0 + i * XROWS;
-    const int64_t m = p_base + r;
-    const int64_t mm = (r < BP && m < p.M) ? m : p.M - 1;  // rows past M: clamped, results never stored
-    const int wo = (int)(mm % p.Wo);
-    const int64_t t = mm / p.Wo;
-    const int ho = (int)(t % p.Ho);
-    const int n = (int)(t / p.Ho);
-    const int y0 = ho * p.sh - p.ph, x0 = wo * p.sw - p.pw;
-    prow[i] = (int64_t)n * p.H * p.W + (int64_t)y0 * p.W + x0;
-    pyx[i] = (int)(((unsigned)y0 << 16) | ((unsigned)x0 & 0xffffu));
-  }
-  const float* wbase = reinterpret_cast<const float*>(p.weight) + (int64_t)z * p.w_zoff;
-  const float* wrow[WPASS];
-#pragma unroll
-  for (int i = 0; i < WPASS; ++i) {
-    const int co = c_base + wrow0 + i * WROWS;
-    wrow[i] = wbase + (int64_t)(co < p.Cout ? co : p.Cout - 1) * p.Kp + pcs * 4;
-  }
-
-  f4 xreg[2][XPASS][2];  // two chunks in flight (hidden loads: valid only after the counted wait in store_x)
-  int xok[2] = {0, 0};   // validity bits of the half octets (2 per pass) of each register set
-
-  // K iterator: tap innermost (see conv_igemm_kernel)
-  int it_ky = 0, it_kx = 0, it_seg = 0, it_rem = 0, it_sbase = 0;
-  auto it_woff = [&]() PP_INLINE_LAMBDA { return (it_ky * p.kw + it_kx) * p.chunks_per_tap * 32 + it_sbase + it_rem * 32; };
-  const float* it_base = reinterpret_cast<const float*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
-  int it_C = p.in_C[0], it_ldc = p.in_ldc[0], it_chunks = p.seg_chunks[0];
-  auto select_segment = [&](int seg) PP_INLINE_LAMBDA {
-#pragma unroll
-    for (int s = 0; s < PP_MAX_SEG; ++s) {
-      if (seg == s) {
-        it_base = reinterpret_cast<const float*>(p.in_ptr[s]) + (int64_t)z * p.in_zoff[s];
-        it_C = p.in_C[s];
-        it_ldc = p.in_ldc[s];
-        it_chunks = p.seg_chunks[s];
-      }
-    }
-  };
-  auto advance = [&]() PP_INLINE_LAMBDA {
-    if (++it_kx == p.kw) {
-      it_kx = 0;
-      if (++it_ky == p.kh) {
-        it_ky = 0;
-        if (++it_rem == it_chunks) {
-          it_rem = 0;
-          it_sbase += it_chunks * 32;
-          if (p.nseg > 1) select_segment(++it_seg);
-        }
-      }
-    }
-  };
-
-  // next chunk of the K iterator: weights -> LDS stage `buf` (DMA), pixels -> registers (unconditional loads;
-  // out-of-image taps and padded channels read a safe address and are zeroed by a select)
-  auto fetch = [&](int wbuf, auto par) PP_INLINE_LAMBDA {
-    constexpr int P = decltype(par)::value;
-    unsigned char* wt = smem + 2 * XSTAGE + wbuf * WSTAGE;
-    const int woff = it_woff();
-#pragma unroll
-    for (int i = 0; i < WPASS; ++i)
-      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
-    const int c0 = it_rem * 32 + xj * 8;
-    const int dy = it_ky * p.dh, dx = it_kx * p.dw;
-    const int64_t tapoff = (int64_t)dy * p.W + dx;
-    const float* cbase = it_base + c0;
-    int okbits = 0;
-#pragma unroll
-    for (int i = 0; i < XPASS; ++i) {
-      const int y = (pyx[i] >> 16) + dy, x = (int)(short)(pyx[i] & 0xffff) + dx;
-      bool ok = true;
-      int64_t pix;
-      if (p.pad_mode == PP_PAD_REPLICATE) {
-        const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
-        const int xc = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
-        pix = prow[i] + (int64_t)(yc - (pyx[i] >> 16)) * p.W + (xc - (int)(short)(pyx[i] & 0xffff));
-      } else {
-        ok = ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
-        pix = prow[i] + tapoff;
-      }
-      // segment channel counts are multiples of 4: each half octet is either fully valid or padding
-      const bool ok0 = ok && (c0 < it_C), ok1 = ok && (c0 + 4 < it_C);
-      const float* src = ok0 ? cbase + pix * it_ldc : it_base;
-      if constexpr (!(PP_ABLATE & 2)) {
-        gload16_hidden(xreg[P][i][0], src);
-        gload16_hidden(xreg[P][i][1], src + (ok1 ? 4 : 0));
-      } else {
-        asm volatile("" : "=v"(xreg[P][i][0]), "=v"(xreg[P][i][1]) : "v"(src), "v"(ok1));
-      }
-      okbits |= (ok0 ? 1 : 0) << (2 * i) | (ok1 ? 2 : 0) << (2 * i);
-    }
-    xok[P] = okbits;
-    advance();
-  };
-  // split the fetched pixels (h: round toward zero, saturating; l: the exact remainder * 2048, round to nearest)
-  // and write one 16-byte octet per plane
-  // `later` = vector-memory instructions this thread issued after the loads of register set P (0 or NLOADS): waiting
-  // until only those are outstanding retires, in order, this chunk's weight copies and pixel loads.
-  auto store_x = [&](auto par, auto later) PP_INLINE_LAMBDA {
-    constexpr int P = decltype(par)::value;
-    unsigned char* xs = smem + P * XSTAGE;
-    wait_vmcnt_hidden<decltype(later)::value>();
-#pragma unroll
-    for (int i = 0; i < XPASS; ++i) {
-      if (BP % XROWS != 0 && xrow0 + i * XROWS >= BP) continue;
-      f4 v[2] = {xreg[P][i][0], xreg[P][i][1]};
-      if (!((xok[P] >> (2 * i)) & 1)) v[0] = f4{0.f, 0.f, 0.f, 0.f};
-      if (!((xok[P] >> (2 * i)) & 2)) v[1] = f4{0.f, 0.f, 0.f, 0.f};
-      h8 h, l;
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
-        if constexpr (!(PP_ABLATE & 8)) {
-          const h2 hh = cvt_pkrtz_f16(c0, c1);
-          h[e] = hh[0];
-          h[e + 1] = hh[1];
-          l[e] = (half_t)((c0 - (float)hh[0]) * LSCALE);
-          l[e + 1] = (half_t)((c1 - (float)hh[1]) * LSCALE);
-        } else {  // no arithmetic: the raw bit patterns
-          const h2 r0 = __builtin_bit_cast(h2, c0), r1 = __builtin_bit_cast(h2, c1);
-          h[e] = r0[0];
-          h[e + 1] = r0[1];
-          l[e] = r1[0];
-          l[e + 1] = r1[1];
-        }
-      }
-      unsigned char* rowp = xs + (xrow0 + i * XROWS) * ROWB;
-      *reinterpret_cast<h8*>(rowp + xoff_h) = h;
-      *reinterpret_cast<h8*>(rowp + xoff_l) = l;
-    }
-  };
-
-  f4 acc[TC][TP], accx[TC][TP];
-#pragma unroll
-  for (int a = 0; a < TC; ++a)
-#pragma unroll
-    for (int b = 0; b < TP; ++b) {
-      acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-      accx[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-    }
-
-  const int frow = lane & 15;
-  const int fgrp = lane >> 4;
-  const int roff_h = (fgrp ^ swz(frow)) << 4;
-  const int roff_l = ((fgrp + 4) ^ swz(frow)) << 4;
-
-  auto compute = [&](int xbuf, int wbuf) PP_INLINE_LAMBDA {
-    const unsigned char* xs = smem + xbuf * XSTAGE + (wp * TP * 16 + frow) * ROWB;
-    const unsigned char* ws = smem + 2 * XSTAGE + wbuf * WSTAGE + (wc * TC * 16 + frow) * ROWB;
-    h8 ah[TC], al[TC], bh[TP], bl[TP];
-#pragma unroll
-    for (int a = 0; a < TC; ++a) {
-      ah[a] = lds_frag(ws + a * 16 * ROWB + roff_h);
-      al[a] = lds_frag(ws + a * 16 * ROWB + roff_l);
-    }
-#pragma unroll
-    for (int b = 0; b < TP; ++b) {
-      bh[b] = lds_frag(xs + b * 16 * ROWB + roff_h);
-      bl[b] = lds_frag(xs + b * 16 * ROWB + roff_l);
-    }
-    // three sweeps over the tile grid: two MFMAs on one accumulator are always TC*TP instructions apart
-#pragma unroll
-    for (int a = 0; a < TC; ++a)
-#pragma unroll
-      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bh[b], acc[a][b]);
-#pragma unroll
-    for (int a = 0; a < TC; ++a)
-#pragma unroll
-      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(ah[a], bl[b], accx[a][b]);
-#pragma unroll
-    for (int a = 0; a < TC; ++a)
-#pragma unroll
-      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(al[a], bh[b], accx[a][b]);
-  };
-
-  const int nstages = p.nchunks;
-  typedef std::integral_constant<int, 0> P0;
-  typedef std::integral_constant<int, 1> P1;
-  fetch(0, P0{});
-  if (nstages > 1) fetch(1, P1{});
-  typedef std::integral_constant<int, 0> L0;
-  typedef std::integral_constant<int, NLOADS> LN;
-  if (nstages > 1) store_x(P0{}, LN{}); else store_x(P0{}, L0{});
-  pp_wait_lgkm0();
-  pp_barrier();
-  // iteration qs (parity P = qs & 1): pixels of chunk qs are in LDS stage P, weights in stage qs % 3; chunk qs+1 is in
-  // registers set 1-P / in flight to weight stage (qs+1) % 3.
-  int w0 = 0;  // qs % 3
-  auto iteration = [&](int qs, auto par) PP_INLINE_LAMBDA {
-    constexpr int P = decltype(par)::value;
-    typedef std::integral_constant<int, 1 - P> Q;
-    const int w1 = w0 == 2 ? 0 : w0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;
-    if (qs + 2 < nstages) fetch(w2, par);  // register set P was stored to LDS one iteration ago
-    compute(P, w0);
-    if (qs + 1 < nstages) {
-      if (qs + 2 < nstages) store_x(Q{}, LN{}); else store_x(Q{}, L0{});
-    }
-    pp_wait_lgkm0();
-    pp_barrier();  // bare barrier: the copies of chunk qs+2 stay in flight across it
-    w0 = w1;
-  };
-  for (int qs = 0; qs < nstages; qs += 2) {
-    iteration(qs, P0{});
-    if (qs + 1 < nstages) iteration(qs + 1, P1{});
-  }
-
-  EpiCtx<OT> e;
-  e.bias = p.bias ? p.bias + (int64_t)z * p.bias_zoff : nullptr;
-  e.out = reinterpret_cast<OT*>(p.out) + (int64_t)z * p.out_zoff;
-  e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
-  e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
-  e.pre = reinterpret_cast<const OT*>(p.pre_add);
-  static_for<TP>([&](auto bi) {
-    constexpr int b = decltype(bi)::value;
-    const int64_t m = p_base + wp * TP * 16 + b * 16 + frow;
-    static_for<TC>([&](auto ai) {
-      constexpr int a = decltype(ai)::value;
-      const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
-      const f4 v = acc[a][b] + accx[a][b] * LINV;
-      if (m < p.M && c < p.Cout) store_quad<OT>(p, e, v, m, c);
-    });
-  });
-}
-
-template <typename OT, int WC, int WP, int TC, int TP>
-static int launch_split_cfg(void* stream, const ConvK& k, int Z) {
-  constexpr int BC = WC * TC * 16;
-  constexpr int BP = WP * TP * 16;
-  constexpr int NT = WC * WP * 64;
-  constexpr int BCP = (BC + NT / 8 - 1) / (NT / 8) * (NT / 8);
-  const size_t smem = (size_t)(2 * BP + 3 * BCP) * 128;
-  dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_split_kernel<OT, WC, WP, TC, TP>), smem), true);
-  (void)lds_ok;
-  PP_LAUNCH((conv_split_kernel<OT, WC, WP, TC, TP>), grid, dim3(NT), smem, stream, k);
-  return pp_check_launch("pp_conv2d");
-}
-
 template <typename T, typename OT, int WC, int WP, int TC, int TP>
 static int launch_cfg(void* stream, const ConvK& k, int Z) {
   // f32: 32x32x2 MFMA tiles whenever the per-wave tile is a multiple of 32x32
@@ -946,52 +457,6 @@ struct IgemmFamily {
   static int run(void* stream, const ConvK& k, int Z) { return launch_cfg<T, OT, WC, WP, TC, TP>(stream, k, Z); }
   static constexpr bool m32_wide96 = sizeof(T) == 4;
 };
-template <typename OT>
-struct SplitFamily {
-  template <int WC, int WP, int TC, int TP>
-  static int run(void* stream, const ConvK& k, int Z) { return launch_split_cfg<OT, WC, WP, TC, TP>(stream, k, Z); }
-  static constexpr bool m32_wide96 = false;
-};
-
-template <typename F>
-static int launch_by_cout(void* stream, const ConvK& k, int Z) {
-  // Small problems (the per-step convolutions of the two recurrences: M = 2*45*80 or 90*160 pixels) would
-  // fill only a fraction of the 256 CUs with 128-pixel tiles: switch to 32-pixel tiles (4x the work-groups).
-  const int64_t blocks128 = ((k.M + 127) / 128) * ((k.Cout + 127) / 128) * Z;
-  // PP_CONV_TILE=large|small pins the choice (tests cover both tile families).  Experiment (not a default yet):
-  // PP_CONV_TILE=xl uses 8-wave 256-channel x 128-pixel tiles when the problem is large
-  // (half the pixel-tile gather per flop); "xlforce" does so regardless of the problem size (tests).
-  static const int forced = [] {
-    const char* e = getenv("PP_CONV_TILE");
-    if (!e) return 0;
-    if (e[0] == 'x') return strcmp(e, "xlforce") == 0 ? 4 : 3;
-    return e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
-  }();
-  const bool small = forced == 2 || ((forced == 0 || forced == 3) && blocks128 < 224);
-  // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would)
-  const bool fits256 = (k.Cout + 255) / 256 * 256 == (k.Cout + 127) / 128 * 128;
-  if (forced >= 3 && fits256 && (forced == 4 || blocks128 >= 1024))
-    return F::template run<4, 2, 4, 4>(stream, k, Z);                                // 256 x 128, 8 waves
-  if (k.Cout > 64) {
-    if (small) return F::template run<4, 1, 2, 2>(stream, k, Z);                     // 128 x  32
-    // 96-wide tiles when they waste clearly fewer output channels than 128-wide ones (Cout 192, 576, ...)
-    const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
-    const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
-    if (waste96 + 32 <= waste128) {                                                  //  96 x 128
-      // f32 MFMA: one wave column of 96 x 32 so that the wave tile is made of 32x32 MFMA blocks
-      if constexpr (F::m32_wide96) return F::template run<1, 4, 6, 2>(stream, k, Z);
-      else return F::template run<2, 2, 3, 4>(stream, k, Z);
-    }
-    return F::template run<2, 2, 4, 4>(stream, k, Z);                                // 128 x 128
-  }
-  if (k.Cout > 32) {
-    if (small) return F::template run<2, 2, 2, 1>(stream, k, Z);                     //  64 x  32
-    return F::template run<1, 4, 4, 2>(stream, k, Z);                                //  64 x 128
-  }
-  if (k.Cout > 16) return F::template run<1, 4, 2, 2>(stream, k, Z);                 //  32 x 128
-  return F::template run<1, 4, 1, 4>(stream, k, Z);                                  //  16 x 256
-}
-
 }  // namespace pp
 
 extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
@@ -1055,7 +520,7 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   }
   if (p->dtype == PP_F32X2) {
     if (p->out_dtype != PP_F32) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: PP_F32X2 writes f32 only");
-    return launch_by_cout<SplitFamily<float>>(stream, k, Z);
+    return launch_split(stream, k, Z);
   }
   if (p->out_dtype == PP_F16) return launch_by_cout<IgemmFamily<float, half_t>>(stream, k, Z);
   return launch_by_cout<IgemmFamily<float, float>>(stream, k, Z);

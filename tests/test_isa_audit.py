@@ -18,7 +18,7 @@ def test_hidden_loads_are_never_touched_in_flight(tmp_path):
     import audit_hidden_loads as A
 
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    src = ROOT / "comfyui_propainter_nodes_amd" / "csrc" / "conv_igemm.hip"
+    src = ROOT / "comfyui_propainter_nodes_amd" / "csrc" / "conv_split.hip"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{ROOT / 'include'}",
            f"-I{src.parent}", "-c", str(src), "-o", str(tmp_path / "conv.o"), "-save-temps=obj"]
     subprocess.run(cmd, check=True, cwd=tmp_path, capture_output=True)

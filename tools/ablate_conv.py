@@ -3,7 +3,7 @@
     python tools/ablate_conv.py --build     # here (CPU): variant libraries tools/ablate/libpp_abl_<mask>.so
     python tools/ablate_conv.py             # on the MI355X (gpurun): time every variant, write gpurun_out/ablate.json
 
-Each variant is the product library with conv_igemm.hip compiled with -DPP_ABLATE=<mask> (pp_device.h: 1 no MFMA,
+Each variant is the product library with conv_igemm.hip / conv_split.hip compiled with -DPP_ABLATE=<mask> (pp_device.h: 1 no MFMA,
 2 no pixel loads, 4 no weight loads, 8 no operand-split arithmetic, 16 no LDS fragment reads, 32 no K-loop barriers).
 The results of an ablated kernel are meaningless; only the time differences are read."""
 import json
@@ -22,16 +22,22 @@ def build():
     from comfyui_propainter_nodes_amd import build as B
 
     B.build_hip()
-    objs = [o for o in (B.PKG / "build" / "hip").glob("*.o") if o.name != "conv_igemm.o"]
-    src = B.CSRC / "conv_igemm.hip"
+    conv = ("conv_igemm", "conv_split")
+    objs = [o for o in (B.PKG / "build" / "hip").glob("*.o") if o.stem not in conv]
 
     def one(mask):
-        obj = OUT / f"conv_igemm_{mask}.o"
+        mine = []
+        for name in conv:
+            obj = OUT / f"{name}_{mask}.o"
+            subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-DPP_ABLATE={mask}",
+                            "-I", str(B.CSRC), "-I", str(ROOT / "include"), "-c", str(B.CSRC / f"{name}.hip"), "-o", str(obj)],
+                           check=True)
+            mine.append(obj)
         so = OUT / f"libpp_abl_{mask}.so"
-        subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-DPP_ABLATE={mask}",
-                        "-I", str(B.CSRC), "-I", str(ROOT / "include"), "-c", str(src), "-o", str(obj)], check=True)
-        subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), str(obj), "-o", str(so)], check=True)
-        obj.unlink()
+        subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), *map(str, mine), "-o", str(so)],
+                       check=True)
+        for obj in mine:
+            obj.unlink()
         return so
 
     OUT.mkdir(exist_ok=True)

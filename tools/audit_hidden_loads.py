@@ -1,8 +1,8 @@
-"""CFG-aware audit of the -save-temps ISA of conv_igemm.hip: between a hidden (inline-asm) global load and the next
+"""CFG-aware audit of the -save-temps ISA of conv_split.hip: between a hidden (inline-asm) global load and the next
 s_waitcnt vmcnt on every execution path, no instruction may read or write the load's destination registers (hipcc
 does not know they are in flight: a register-allocator copy or reuse there would silently corrupt the tile).
 
-Usage: hipcc ... -c conv_igemm.hip -save-temps=obj ; python tools/audit_hidden_loads.py <file.s>"""
+Usage: hipcc ... -c conv_split.hip -save-temps=obj ; python tools/audit_hidden_loads.py <file.s>"""
 import re
 import sys
 
@@ -95,4 +95,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else "/tmp/conv_igemm-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else "/tmp/conv_split-hip-amdgcn-amd-amdhsa-gfx950.s"))
