@@ -211,8 +211,9 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
     return e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
   }();
   const bool small = forced == 2 || ((forced == 0 || forced == 3) && blocks128 < 224);
-  // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would)
-  const bool fits256 = (k.Cout + 255) / 256 * 256 == (k.Cout + 127) / 128 * 128;
+  // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would, and at most 1/8)
+  const int waste256 = (k.Cout + 255) / 256 * 256 - k.Cout;
+  const bool fits256 = (k.Cout + 255) / 256 * 256 == (k.Cout + 127) / 128 * 128 && waste256 * 8 <= k.Cout;
   if (forced >= 3 && fits256 && (forced == 4 || blocks128 >= 1024))
     return F::template run<4, 2, 4, 4>(stream, k, Z);                                // 256 x 128, 8 waves
   if (k.Cout > 64) {
