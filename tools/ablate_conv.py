@@ -54,38 +54,51 @@ SHAPES = [
 ]
 
 
-def run():
+def run_one(mask: int) -> None:
+    """Time every shape with one variant library (child process: a faulting variant must not take the others down)."""
     import torch
 
     from comfyui_propainter_nodes_amd import lib, ops
 
     dev = torch.device("cuda:0")
-    variants = [(0, lib.HIP_LIB)] + [(m, OUT / f"libpp_abl_{m}.so") for m in MASKS if (OUT / f"libpp_abl_{m}.so").exists()]
+    path = lib.HIP_LIB if mask == 0 else OUT / f"libpp_abl_{mask}.so"
+    lib._lib = lib.Library(path, is_emulator=False)
+    row = {}
+    for name, split, f16, N, H, W, segC, Cout, k, p in SHAPES:
+        dt = torch.float16 if f16 else torch.float32
+        x = [torch.randn(N, H, W, c, device=dev).to(dt) for c in segC]
+        w = torch.randn(Cout, sum(segC), *k) * 0.05
+        spec = ops.make_conv_spec(w, torch.zeros(Cout), dt, padding=p, seg_channels=segC, split=split).to(dev)
+        out = torch.empty(N, *spec.out_hw(H, W), Cout, device=dev, dtype=dt)
+        for _ in range(3):
+            ops.conv2d(spec, x, out, act="relu")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.conv2d(spec, x, out, act="relu")
+        e1.record()
+        torch.cuda.synchronize()
+        row[name] = round(e0.elapsed_time(e1) / 10, 4)
+    print("ABLATE_ROW " + json.dumps({"mask": mask, "ms": row}), flush=True)
+
+
+def run():
     res = {}
-    for mask, path in variants:
-        lib._lib = lib.Library(path, is_emulator=False)
-        row = {}
-        for name, split, f16, N, H, W, segC, Cout, k, p in SHAPES:
-            dt = torch.float16 if f16 else torch.float32
-            x = [torch.randn(N, H, W, c, device=dev).to(dt) for c in segC]
-            w = torch.randn(Cout, sum(segC), *k) * 0.05
-            spec = ops.make_conv_spec(w, torch.zeros(Cout), dt, padding=p, seg_channels=segC, split=split).to(dev)
-            out = torch.empty(N, *spec.out_hw(H, W), Cout, device=dev, dtype=dt)
-            for _ in range(3):
-                ops.conv2d(spec, x, out, act="relu")
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                ops.conv2d(spec, x, out, act="relu")
-            e1.record()
-            torch.cuda.synchronize()
-            row[name] = round(e0.elapsed_time(e1) / 10, 4)
-        res[str(mask)] = row
-        print(mask, row, flush=True)
+    masks = [0] + [m for m in MASKS if (OUT / f"libpp_abl_{m}.so").exists()]
+    for mask in masks:
+        r = subprocess.run([sys.executable, __file__, "--one", str(mask)], capture_output=True, text=True, timeout=120)
+        rows = [ln for ln in r.stdout.splitlines() if ln.startswith("ABLATE_ROW ")]
+        res[str(mask)] = json.loads(rows[-1][len("ABLATE_ROW "):])["ms"] if rows else {"error": (r.stderr or r.stdout)[-300:]}
+        print(mask, res[str(mask)], flush=True)
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
     (ROOT / "gpurun_out" / "ablate.json").write_text(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    build() if "--build" in sys.argv else run()
+    if "--build" in sys.argv:
+        build()
+    elif "--one" in sys.argv:
+        run_one(int(sys.argv[sys.argv.index("--one") + 1]))
+    else:
+        run()
