@@ -78,7 +78,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(const ConvK p)
   // NST == 3: two chunks in flight across the (single) barrier per chunk; the MFMA phase of one chunk is too
   // short to hide a global->LDS round trip with only one chunk ahead.
   constexpr int NST = G::NST;
-  constexpr int NLOADS = XPASS + WPASS;  // global_load_lds instructions per thread per chunk
+  // global_load_lds instructions per thread per chunk (ablation builds count only what they issue)
+  constexpr int NLOADS = ((PP_ABLATE & 2) ? 0 : XPASS) + ((PP_ABLATE & 4) ? 0 : WPASS);
   typedef typename Frag<T>::piece piece_t;
 
   T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);  // [2 stages][KC][ X: BP rows | W: BC rows ][LDK]

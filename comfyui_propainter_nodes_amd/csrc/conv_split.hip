@@ -30,7 +30,9 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
   // LDS: 2 pixel stages + 3 weight stages.  Pixels of chunk q+2 are in flight to registers and weights of chunk
   // q+2 in flight to LDS while chunk q is multiplied: two chunks of latency cover per work-group.
   constexpr int XSTAGE = BP * ROWB, WSTAGE = BCP * ROWB;
-  constexpr int NLOADS = WPASS + 2 * XPASS;  // vector-memory instructions per thread per chunk
+  // vector-memory instructions per thread per chunk (an ablation build that drops loads must also stop counting them:
+  // a hidden load that lands after its too-lenient wait overwrites a register the compiler has already re-purposed)
+  constexpr int NLOADS = ((PP_ABLATE & 4) ? 0 : WPASS) + ((PP_ABLATE & 2) ? 0 : 2 * XPASS);
   constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
 
   unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
