@@ -70,8 +70,9 @@ const char* pp_last_error(void);
 int64_t pp_struct_size(const char* name);
 
 /* ------------------------------------------------------------------------------------
- * pp_conv2d -- implicit-GEMM convolution on MFMA (f16 inputs: 16x16x32, f32 inputs:
- * 16x16x4 exact-f32), fp32 accumulate, fused bias/activation/epilogue.
+ * pp_conv2d -- implicit-GEMM convolution on MFMA (f16 inputs: 16x16x32; f32 inputs: 32x32x2 /
+ * 16x16x4 exact-f32 products, or PP_F32X2: three f16 products per multiply-add), fp32
+ * accumulate, fused bias/activation/epilogue.
  * Replaces every torch.nn.Conv2d / Conv3d(1,k,k) / Conv3d(3,1,1) / Linear / matmul on
  * the hot path: RAFT extractor.py:170-193, update.py:6-154, corr.py:52-60 (volume as a
  * batched 1x1), recurrent_flow_completion.py:17-26,69-75,162-300, propainter.py:48-57,
