@@ -148,6 +148,82 @@ def test_conv2d_random_geometries_under_emulation(tile, seed):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_conv2d_random_epilogues(emu_lib):
+    """(Emulator only this round: not yet run on the MI355X; switch the fixture to `backend` once it has been.)
+    Seeded random epilogue configurations: channel counts that leave partial quads, output / aux / pre_add views at
+    channel offsets that break the 16-byte alignment of the vector path, every fused op, two-activation splits that
+    straddle a quad, out_scale -- against float64 torch."""
+    import os
+    import random
+
+    dev = torch.device("cpu")
+    rnd = random.Random(int(os.environ.get("PP_EPI_FUZZ_SEED", "2024")))
+    g = torch.Generator().manual_seed(99)
+    acts = {None: lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+    ncase = int(os.environ.get("PP_EPI_FUZZ_N", "24" if dev.type == "cpu" else "60"))
+    for _ in range(ncase):
+        mode = rnd.choice(["f32", "f16", "f32x2"])
+        dt = torch.float16 if mode == "f16" else torch.float32
+        cin = (8 if mode == "f16" else 4) * rnd.randint(1, 5)
+        cout = rnd.choice([3, 5, 16, 22, 37, 64, 70, 129])
+        H, W = rnd.randint(4, 9), rnd.randint(4, 11)
+        x = torch.randn(1, H, W, cin, generator=g).to(dt)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+        b = torch.randn(cout, generator=g) if rnd.random() < 0.8 else None
+        spec = ops.make_conv_spec(w, b, dt, padding=1, split=(mode == "f32x2")).to(dev)
+        odt = dt
+
+        def view(off, extra):  # a channel slice of a wider buffer: ldc = cout + extra, first channel at `off`
+            buf = torch.full((1, H, W, cout + extra), 3.0, dtype=odt)
+            return buf, buf[..., off:off + cout]
+
+        ooff, oext = rnd.choice([(0, 0), (4, 8), (1, 3), (2, 5), (0, 4)])
+        obuf, _ = view(ooff, oext)
+        obuf = obuf.to(dev)
+        out = obuf[..., ooff:ooff + cout]
+        act = rnd.choice(list(acts))
+        act2, split = None, 0
+        if rnd.random() < 0.35 and cout > 8:
+            act2, split = rnd.choice(["sigmoid", "relu", "tanh"]), rnd.randint(1, cout - 1)
+        scale = rnd.choice([0.0, 0.0, 5.0, 0.25])
+        epi = rnd.choice([None, None, "mul", "add", "add_relu", "gru"])
+        a1 = a2 = pre = None
+        aoff, aext = rnd.choice([(0, 0), (4, 4), (3, 5)])
+        if epi:
+            a1 = torch.rand(1, H, W, cout + aext, generator=g).to(odt)[..., aoff:aoff + cout]
+            if epi == "gru":
+                a2 = torch.randn(1, H, W, cout + aext, generator=g).to(odt)[..., aoff:aoff + cout]
+        if rnd.random() < 0.4:
+            pre = torch.randn(1, H, W, cout + aext, generator=g).to(odt)[..., aoff:aoff + cout]
+        ops.conv2d(spec, [x.to(dev)], out, act=act, act_param=0.2, act2=act2, act_split=split, out_scale=scale, epi=epi,
+                   aux1=None if a1 is None else a1.to(dev), aux2=None if a2 is None else a2.to(dev),
+                   pre_add=None if pre is None else pre.to(dev))
+        v = F.conv2d(x.double().permute(0, 3, 1, 2), w.to(dt).double(), None if b is None else b.double(), padding=1).permute(0, 2, 3, 1)
+        if pre is not None:
+            v = v + pre.double()
+        if split > 0:
+            lo = acts[act](v[..., :split])
+            lo = lo * scale if scale != 0.0 else lo
+            v = torch.cat([lo, acts[act2](v[..., split:])], -1)
+        else:
+            v = acts[act](v)
+            v = v * scale if scale != 0.0 else v
+        if epi == "mul":
+            v = v * a1.double()
+        elif epi == "add":
+            v = v + a1.double()
+        elif epi == "add_relu":
+            v = F.relu(v + a1.double())
+        elif epi == "gru":
+            v = (1 - a1.double()) * a2.double() + a1.double() * v
+        got = out.double().cpu()
+        tol = (3e-5 if dt == torch.float32 else 6e-3) * max(1.0, v.abs().max().item())
+        cfg = (mode, cin, cout, act, act2, split, scale, epi, ooff, oext, aoff, aext, pre is not None)
+        assert (got - v).abs().max().item() <= tol, (cfg, (got - v).abs().max().item())
+        full = obuf.double().cpu()
+        assert torch.all(full[..., :ooff] == 3.0) and torch.all(full[..., ooff + cout:] == 3.0), cfg  # neighbours untouched
+
+
 def test_conv2d_epilogues(backend):
     dev = backend
     g = torch.Generator().manual_seed(7)
