@@ -208,15 +208,18 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
     const char* e = getenv("PP_CONV_TILE");
     if (!e) return 0;
     if (e[0] == 'x') return strcmp(e, "xlforce") == 0 ? 4 : 3;
+    if (e[0] == 't') return 5;  // "tiny": experiment, 16-pixel tiles for problems that leave CUs idle even with 32
     return e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
   }();
-  const bool small = forced == 2 || ((forced == 0 || forced == 3) && blocks128 < 224);
+  const bool small = forced == 2 || ((forced == 0 || forced == 3 || forced == 5) && blocks128 < 224);
   // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would, and at most 1/8)
   const int waste256 = (k.Cout + 255) / 256 * 256 - k.Cout;
   const bool fits256 = (k.Cout + 255) / 256 * 256 == (k.Cout + 127) / 128 * 128 && waste256 * 8 <= k.Cout;
   if (forced >= 3 && fits256 && (forced == 4 || blocks128 >= 1024))
     return F::template run<4, 2, 4, 4>(stream, k, Z);                                // 256 x 128, 8 waves
   if (k.Cout > 64) {
+    // experiment (PP_CONV_TILE=tiny): 16-pixel tiles when 32-pixel tiles still give at most ~1 work-group per CU
+    if (forced == 5 && blocks128 * 4 < 320) return F::template run<4, 1, 2, 1>(stream, k, Z);  // 128 x 16
     if (small) return F::template run<4, 1, 2, 2>(stream, k, Z);                     // 128 x  32
     // 96-wide tiles when they waste clearly fewer output channels than 128-wide ones (Cout 192, 576, ...)
     const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;

@@ -51,7 +51,7 @@ def _ref_input(x, segC, groups):
 
 
 # ("xlforce" = the experimental 8-wave 256-channel tiles: emulator only until they have been measured on the MI355X)
-@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"),
+@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"),
                                      pytest.param("hip", "large", marks=pytest.mark.gpu),
                                      pytest.param("hip", "small", marks=pytest.mark.gpu)])
 def test_conv2d_matches_torch(be, tile):
@@ -134,7 +134,7 @@ def _run_case(backend, case):
     assert torch.all(buf[..., :4].float().cpu() == 7.0) and torch.all(buf[..., 4 + Cout * groups:].float().cpu() == 7.0)
 
 
-@pytest.mark.parametrize("tile,seed", [("large", 11), ("small", 12), ("xlforce", 13)])
+@pytest.mark.parametrize("tile,seed", [("large", 11), ("small", 12), ("xlforce", 13), ("tiny", 14)])
 def test_conv2d_random_geometries_under_emulation(tile, seed):
     import os
     import subprocess
