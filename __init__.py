@@ -1,7 +1,8 @@
 """ComfyUI custom-node entry point (drop this repository into ComfyUI/custom_nodes/)."""
-try:
+if __package__:
+    # loaded by ComfyUI as a package: any failure inside the import (missing library, scipy, PIL ...) must surface as is
     from .comfyui_propainter_nodes_amd.nodes import NODE_CLASS_MAPPINGS, NODE_DISPLAY_NAME_MAPPINGS
-except ImportError:  # imported as a top-level module (tests, bench)
+else:  # imported as a top-level module (tests, bench)
     from comfyui_propainter_nodes_amd.nodes import NODE_CLASS_MAPPINGS, NODE_DISPLAY_NAME_MAPPINGS
 
 __all__ = ["NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"]

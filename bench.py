@@ -5,19 +5,26 @@
 One "step" = one full pass of the hot path (RAFT -> flow completion -> image propagation ->
 feature propagation + sparse transformer -> uint8 compose) over one synthetic clip of
 BASELINE.json configs[1]: 80 frames, 640x360, neighbor_length 10, ref_stride 10, subvideo_length 80,
-raft_iter 20 (node default), fp16 "enable" (RAFT fp32 like the reference).  Inputs (uint8 frames +
-masks) are resident in HBM when the timed region starts; the composed uint8 frames stay in HBM.
-Weights: pretrained checkpoints when `weights/` holds them, else seeded random weights of the exact
-architecture (no network here) -- stated in `data`.
+raft_iter 20 (node default), fp16 "enable" (RAFT fp32 like the reference).  `value` follows the bench
+contract: inputs (uint8 frames + masks) are resident in HBM when the timed region starts and the composed
+uint8 frames stay in HBM.  SURVEY.md 8d's node-level metric (the node METHOD from call to return: H2D of the
+fp32 IMAGE / MASK, device-side uint8 / mask plumbing, the pipeline, uint8 -> fp32 and D2H of the result,
+models cached) is measured in the same run and reported beside it as `node_call` (PCIe-inclusive, so by the
+contract it is not `value`).  Weights: pretrained checkpoints when `weights/` holds them, else seeded random
+weights of the exact architecture (no network here) -- stated in `data`.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): ONE clip of 80*N frames is sharded
-into the reference's own 80-frame sub-videos, one per rank (BASELINE.json configs[3] at N = 8), with the
-seam exchanges of comfyui_propainter_nodes_amd/distributed.py (all_gather over xGMI) inside the timed region -- weak scaling
-(frames per GPU fixed); barrier + synchronize on both sides, MAX over ranks.
+N > 1: one rank per GPU over RCCL.  Launched by `torch.distributed.run` (the driver) the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE; run bare (`python bench.py --gpus N`) the script re-executes itself under
+`torch.distributed.run --nproc-per-node N`.  ONE clip of 80*N frames is sharded into the reference's own
+80-frame sub-videos, one per rank (BASELINE.json configs[3] at N = 8), with the seam exchanges of
+comfyui_propainter_nodes_amd/distributed.py inside the timed region -- weak scaling (frames per GPU fixed);
+barrier + synchronize on both sides, MAX over ranks.
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (the MFMA implicit-GEMM conv),
-measured live with HIP events on the launch stream during one extra instrumented step, and
-`cpu_baseline` (the oracle = CPU port of the reference, bounded sample, rank 0 at N=1 only).
+Extra objects on the JSON line (N = 1): `roofline` for the dominant kernel (the MFMA implicit-GEMM conv),
+measured live with HIP events on the launch stream during one extra instrumented step; `cpu_baseline` (the
+oracle = CPU port of the reference, bounded sample); `parity` (the GPU result of that same sample against the
+oracle's: PSNR / max LSB of the composed frames, max flow error); `node_call`; `f32_exact` (frames/s with
+PP_F32_GEMM=exact, i.e. RAFT on the f32 MFMA instructions instead of the f16x2 operand split).
 """
 from __future__ import annotations
 
@@ -53,8 +60,10 @@ def make_inputs(T, H, W, mask_dilates, flow_mask_dilates, seed=1234):
     return image_utils.prepare_frames_and_masks(frames_u8, mask, icfg)
 
 
-def cpu_baseline(sds, n_frames=12):
-    """Time the oracle (CPU port of the reference algorithm) on a bounded sample of the same workload."""
+def cpu_baseline(sds, models, dev, n_frames=12):
+    """Time the oracle (CPU port of the reference algorithm) on a bounded sample of the same workload, and compare the
+    GPU result on the SAME sample with it (the oracle here is the checker, never the thing measured as `value`)."""
+    from comfyui_propainter_nodes_amd import pipeline
     from oracle import pipeline as OP
 
     # a bounded thread count: the GPU box exposes 256 hardware threads and torch's CPU kernels on the small
@@ -65,12 +74,71 @@ def cpu_baseline(sds, n_frames=12):
     fmt = torch.from_numpy(fm).float()[None, :, None]
     mdt = torch.from_numpy(md).float()[None, :, None]
     t0 = time.time()
-    OP.run(sds, frames, fmt, mdt, [f for f in frames_u8], raft_iter=CFG["raft_iter"], neighbor_length=CFG["neighbor_length"],
-           ref_stride=CFG["ref_stride"], subvideo_length=CFG["subvideo_length"])
+    ref, otr = OP.run(sds, frames, fmt, mdt, [f for f in frames_u8], raft_iter=CFG["raft_iter"],
+                      neighbor_length=CFG["neighbor_length"], ref_stride=CFG["ref_stride"],
+                      subvideo_length=CFG["subvideo_length"], return_trace=True)
     dt = time.time() - t0
-    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    base = {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{n_frames}-frame 640x360 clip, raft_iter {CFG['raft_iter']}, fp32, oracle/ (CPU restatement of the "
                       f"reference), {dt:.1f} s"}
+    cfg = pipeline.ProPainterConfig(CFG["ref_stride"], CFG["neighbor_length"], CFG["subvideo_length"], CFG["raft_iter"],
+                                    "enable", n_frames, dev, (CFG["W"], CFG["H"]))
+    tr = {}
+    got = pipeline.run_inpainting(models, frames_u8, fm, md, cfg, trace=tr).numpy()
+    ref = np.stack(ref, 0)
+    sel = md.astype(bool)
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    mse = float((d[sel].astype(np.float64) ** 2).mean())
+    e_gt = max(float((tr["gt_flows"][i].cpu() - otr["gt_flows"][i][0].permute(0, 2, 3, 1)).abs().max()) for i in (0, 1))
+    e_pf = max(float((tr["pred_flows"][i].cpu() - otr["pred_flows"][i][0].permute(0, 2, 3, 1)).abs().max()) for i in (0, 1))
+    parity = {"vs": "oracle/ (fp32 CPU) on the cpu_baseline sample", "psnr_db": round(99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse), 2),
+              "psnr_over": "pixels inside the dilated mask (outside it the frames are the input, bit-exact: "
+                           + str(bool(np.array_equal(got[~sel], ref[~sel]))).lower() + ")",
+              "max_lsb": int(d.max()), "frac_gt_2lsb": round(float((d[sel] > 2).mean()), 6),
+              "flow_max_px": round(e_gt, 6), "completed_flow_max_px": round(e_pf, 6),
+              "updated_mask_mismatch": round(float((tr["updated_masks"].cpu() != otr["updated_masks"][0, :, 0].to(torch.uint8)).float().mean()), 6)}
+    return base, parity
+
+
+def node_call_timing(dev, reps=3):
+    """the node method from call to return on the configs[1] clip (host fp32 IMAGE / MASK in, host fp32
+    IMAGE out), models cached; returns frames/s, ms and the stage breakdown of the last call."""
+    from comfyui_propainter_nodes_amd import nodes, synth
+
+    image, mask = synth.synthetic_clip(CFG["T"], CFG["H"], CFG["W"], 1234)
+    node = nodes.ProPainterInpaint()
+    args = (image, mask, CFG["W"], CFG["H"], CFG["mask_dilates"], CFG["flow_mask_dilates"], CFG["ref_stride"],
+            CFG["neighbor_length"], CFG["subvideo_length"], CFG["raft_iter"], "enable")
+    node.propainter_inpainting(*args)  # warm: model cache, allocator
+    nodes._Timer.collect = True
+    times = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = node.propainter_inpainting(*args)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    nodes._Timer.collect = False
+    best = min(times)
+    return {"frames_per_s": round(CFG["T"] / best, 2), "ms": round(best * 1e3, 1), "reps": reps,
+            "what": "ProPainterInpaint.propainter_inpainting call-to-return: host fp32 IMAGE/MASK -> host fp32 IMAGE "
+                    "(H2D, device uint8/mask plumbing, pipeline, uint8->fp32, D2H), models cached",
+            "breakdown_ms": nodes._Timer.last, "out_shape": list(out[0].shape)}
+
+
+def respawn_under_torchrun(n: int) -> int:
+    """`python bench.py --gpus N` run bare: launch N ranks (one per GPU) of this script under torch.distributed.run."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -80,13 +148,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=CFG["T"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the node_call / f32_exact legs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    if world > 1 and os.environ.get("PP_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, {torch.cuda.device_count()} visible")
+    os.environ["PP_ALLOW_SYNTHETIC_WEIGHTS"] = "1"  # explicit opt-in: no checkpoints can be downloaded here (stated in `data`)
     dev_index = local_rank % torch.cuda.device_count()  # (PP_DIST_BACKEND=gloo lets 2 ranks share one GPU for functional tests)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -109,6 +185,7 @@ def main():
     sds, prov = weights.get_state_dicts(0)
     models = pipeline.models_from_state_dicts(sds, dev)
     T = args.frames * world
+    CFG["subvideo_length"] = min(CFG["subvideo_length"], args.frames)  # (--frames < 80: one sub-video per rank all the same)
     frames_u8, fm, md = make_inputs(T, CFG["H"], CFG["W"], CFG["mask_dilates"], CFG["flow_mask_dilates"], seed=1234)
     cfg = pipeline.ProPainterConfig(CFG["ref_stride"], CFG["neighbor_length"], CFG["subvideo_length"], CFG["raft_iter"],
                                     "enable", T, dev, (CFG["W"], CFG["H"]))
@@ -156,7 +233,8 @@ def main():
     dom = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
     roofline = None
     traffic = None
-    tfile = ROOT / "profiles" / "r01_traffic.json"
+    tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+    tfile = tfiles[-1] if tfiles else ROOT / "profiles" / "none"
     if tfile.exists():  # PMC passes cannot run inside bench.py: the committed rocprofv3 result of the same kernel
         fam = json.loads(tfile.read_text()).get("families", {})
         if dom in fam:
@@ -167,7 +245,7 @@ def main():
         roofline = {"kernel": KERNEL_NAME[dom], "bound": "mfma",
                     "achieved": round(ach, 2), "peak": round(PEAK_TFLOPS[dom], 1), "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS[dom], 4),
-                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
+                    "traffic": traffic, "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{tfile.name})",
                     "algorithmic_bytes_per_launch": d["bytes"] / d["n"], "launches": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / d["n"], 2),
                     "flops_per_launch": d["flops"] / d["n"], "share_of_step_ms": round(d["ms"], 1),
                     "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 1), "launches": v["n"]}
@@ -178,13 +256,28 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 (RAFT: f32 tensors, f16x2-split MFMA products), fp32 accumulate",
         "data": f"synthetic clip (seeded texture + sinusoidal motion, centre box mask); weights: {prov}",
-        "config": {"workload": f"{T}-frame 640x360 clip, neighbor_length 10, ref_stride 10, subvideo_length 80, raft_iter 20, "
+        "config": {"workload": f"{T}-frame 640x360 clip, neighbor_length 10, ref_stride 10, subvideo_length {CFG['subvideo_length']}, raft_iter 20, "
                                f"fp16 enable (BASELINE.json configs[{1 if world == 1 else 3}])", "frames_per_gpu": T // world,
                    "parallelism": f"subvideo x{world}" + (" (one clip, seam all_gather over RCCL)" if world > 1 else "")},
         "roofline": roofline,
     }
+    if rank == 0 and world == 1 and not args.no_extras:
+        line["node_call"] = node_call_timing(dev)
+        # RAFT on the f32 MFMA instructions (bit-exact fp32 products) instead of the f16x2 operand split
+        os.environ["PP_F32_GEMM"] = "exact"
+        exact = pipeline.models_from_state_dicts(sds, dev)
+        del os.environ["PP_F32_GEMM"]
+        pipeline.run_inpainting(exact, fr_d, fm_d, md_d, cfg, to_host=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            pipeline.run_inpainting(exact, fr_d, fm_d, md_d, cfg, to_host=False)
+        torch.cuda.synchronize()
+        line["f32_exact"] = {"value": round(2 * T / (time.perf_counter() - t0), 3), "unit": "frames/s",
+                             "what": "same step with PP_F32_GEMM=exact (RAFT convolutions on v_mfma_f32_32x32x2_f32)"}
+        del exact
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(sds)
+        line["cpu_baseline"], line["parity"] = cpu_baseline(sds, models, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

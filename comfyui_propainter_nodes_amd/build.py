@@ -2,9 +2,8 @@
 
 `python -m comfyui_propainter_nodes_amd.build` compiles every `csrc/*.hip` translation unit
 for gfx950 and links `comfyui_propainter_nodes_amd/libpropainter_mi355.so`.  hipcc cross-compiles without a
-GPU, so this also runs in the build container.  `--emu` additionally builds the
-test-only x86 emulation of the same sources (tests/emu/libpropainter_emu.so); the product
-never loads that library.
+GPU, so this also runs in the build container.  (The test-only x86 emulation of the same
+sources is built by tests/emu/loader.py; nothing in this package knows about it.)
 """
 from __future__ import annotations
 
@@ -19,11 +18,8 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpropainter_mi355.so"
-EMU_DIR = ROOT / "tests" / "emu"
-EMU_LIB = EMU_DIR / "libpropainter_emu.so"
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HOST_CLANG = os.environ.get("PP_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 def _sources() -> list[Path]:
@@ -86,31 +82,10 @@ def build_hip(force: bool = False) -> Path:
     return _compile_all(PKG / "build" / "hip", compile_one, link, LIB, "hip" + " ".join(flags), force)
 
 
-def build_emu(force: bool = False) -> Path:
-    """TEST ONLY: the same kernel sources compiled for x86 against tests/emu/pp_emu.h."""
-    flags = ["-O2", "-std=c++17", "-fPIC", "-DPP_EMU", "-x", "c++", "-Wno-unused-value", "-ffp-contract=off",
-             "-I", str(CSRC), "-I", str(ROOT / "include"), "-I", str(EMU_DIR)]
-
-    def compile_one(src: Path, obj: Path) -> None:
-        _run([HOST_CLANG, *flags, "-c", str(src), "-o", str(obj)])
-
-    def link(objs: list[Path], out: Path) -> None:
-        rt = EMU_DIR / "build" / "pp_emu_rt.o"
-        _run([HOST_CLANG, "-O2", "-std=c++17", "-fPIC", "-I", str(EMU_DIR), "-c",
-              str(EMU_DIR / "pp_emu.cpp"), "-o", str(rt)])
-        _run([HOST_CLANG, "-shared", "-fPIC", *map(str, objs), str(rt), "-lpthread", "-o", str(out)])
-
-    extra = "emu" + " ".join(flags) + (EMU_DIR / "pp_emu.h").read_text() + (EMU_DIR / "pp_emu.cpp").read_text()
-    return _compile_all(EMU_DIR / "build", compile_one, link, EMU_LIB, extra, force)
-
-
 def main(argv: list[str]) -> int:
     force = "--force" in argv
     out = build_hip(force)
     print(f"built {out}")
-    if "--emu" in argv:
-        out = build_emu(force)
-        print(f"built {out}")
     return 0
 
 

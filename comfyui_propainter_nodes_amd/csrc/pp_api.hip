@@ -67,5 +67,10 @@ extern "C" int64_t pp_struct_size(const char* name) {
   PP_SIZEOF_CASE(pp_fold_params)
   PP_SIZEOF_CASE(pp_unfold_gelu_params)
   PP_SIZEOF_CASE(pp_compose_u8_params)
+  PP_SIZEOF_CASE(pp_frames_from_image_params)
+  PP_SIZEOF_CASE(pp_image_from_u8_params)
+  PP_SIZEOF_CASE(pp_mask_dilate_params)
+  PP_SIZEOF_CASE(pp_clip_masks_params)
+  PP_SIZEOF_CASE(pp_window_flags_params)
   return -1;
 }

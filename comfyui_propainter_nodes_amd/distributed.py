@@ -134,11 +134,11 @@ class GpuBackend:
 
     def compose(self, comp, pred, frame_ids, first, md, frames_u8):
         dev = comp.device
-        ops.compose_u8(pred.contiguous(), torch.tensor(frame_ids, dtype=torch.int32, device=dev),
-                       torch.tensor(first, dtype=torch.int32, device=dev), md, frames_u8, comp)
+        ops.compose_u8(pred.contiguous(), ops.device_ints(frame_ids, dev, torch.int32),
+                       ops.device_ints(first, dev, torch.int32), md, frames_u8, comp)
 
     def to_frames(self, frames_u8):             # uint8 -> fp32 in [-1,1]  (image_utils.py:191)
-        return frames_u8.float().div(255) * 2 - 1
+        return ops.frames_from_u8(frames_u8.contiguous())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -15,7 +15,6 @@ from __future__ import annotations
 import math
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -37,7 +36,7 @@ class ClipState:
         self.aux_b = None      # f16 [T-1,h,w,8] (flow_f, fb-valid, masks of frame t)    -> backward pass at frame t
         self.aux_f = None      # f16 [T-1,h,w,8] (flow_b, fb-valid, masks of frame t+1)  -> forward pass at frame t+1
         self.maskpair = None   # f16 [T,h,w,8] (m_in, m_updated, 0...)
-        self.tokmask = None    # bool [T,fh,fw]: MaxPool2d(7,3,3) of the 1/4-res dilated mask
+        self.tokmask = None    # u8 [T,fh,fw]: MaxPool2d(7,3,3) of the 1/4-res dilated mask
         self.H = self.W = 0
 
 
@@ -159,17 +158,12 @@ class InpaintGeneratorMI355:
         ds = torch.empty(2 * (T - 1), h, w, 2, device=dev)
         ops.flow_down4(flows.view(2 * (T - 1), H, W, 2), ds)
         st.flow_f, st.flow_b = ds[:T - 1], ds[T - 1:]
-        # nearest x1/4 picks pixel (4i, 4j) (propainter.py:409-417)
-        st.maskpair = torch.zeros(T, h, w, 8, device=dev, dtype=F16)
-        st.maskpair[..., 0] = masks_in_u8[:, ::4, ::4]
-        st.maskpair[..., 1] = masks_upd_u8[:, ::4, ::4]
+        # nearest x1/4 mask planes + MaxPool2d(7,3,3) token masks (propainter.py:409-428): binary plumbing on the device
+        st.maskpair, st.tokmask = ops.clip_masks(masks_in_u8.contiguous(), masks_upd_u8.contiguous(), *token_grid(h, w))
         st.aux_b = torch.empty(T - 1, h, w, 8, device=dev, dtype=F16)
         st.aux_f = torch.empty(T - 1, h, w, 8, device=dev, dtype=F16)
         ops.featprop_aux(st.flow_f, st.flow_b, st.maskpair[:T - 1], st.aux_b)
         ops.featprop_aux(st.flow_b, st.flow_f, st.maskpair[1:], st.aux_f)
-        # token masks: MaxPool2d(7,3,3) of the 1/4-res dilated mask (:419-428) -- binary plumbing, kept on device
-        m4 = masks_in_u8[:, ::4, ::4].float().unsqueeze(1)
-        st.tokmask = F.max_pool2d(m4, 7, 3, 3)[:, 0] > 0
         return st
 
     # ------------------------------------------------------------------------------------------------
@@ -194,10 +188,9 @@ class InpaintGeneratorMI355:
         dev = st.enc.device
         nw = len(g0s)
         _, h, w, _ = st.enc.shape
-        g0 = torch.tensor(g0s, device=dev)
 
         def gather(t: torch.Tensor, idx: int) -> torch.Tensor:
-            return t.index_select(0, g0 + idx)  # [nw, ...] rows of the per-clip tensor (plain copy)
+            return t.index_select(0, ops.device_ints([g + idx for g in g0s], dev))  # [nw, ...] rows (plain copy)
 
         def buf(c, dt=F16):
             return torch.empty(nw, h, w, c, device=dev, dtype=dt)
@@ -278,13 +271,7 @@ class InpaintGeneratorMI355:
     def window_mask_flags(self, st: ClipState, nb: list[int]) -> torch.Tensor:
         """Integer logic of sparse_transformer.py:321-326: a 5x9 token window is 'masked' iff any
         local-frame token mask inside it is set (computed on the device, no host sync)."""
-        tm = st.tokmask[nb[0]:nb[0] + len(nb)].any(0)  # [fh,fw]
-        fh, fw = tm.shape
-        Hp, Wp = math.ceil(fh / WIN[0]) * WIN[0], math.ceil(fw / WIN[1]) * WIN[1]
-        pad = torch.zeros(Hp, Wp, dtype=torch.bool, device=tm.device)
-        pad[:fh, :fw] = tm
-        flags = pad.view(Hp // WIN[0], WIN[0], Wp // WIN[1], WIN[1]).permute(0, 2, 1, 3).reshape(-1, WIN[0] * WIN[1]).any(1)
-        return flags.to(torch.int32).contiguous()
+        return ops.window_flags(st.tokmask, nb[0], len(nb), WIN)
 
     def forward_window(self, st: ClipState, nb: list[int], refs: list[int], trace: dict | None = None,
                        local_prop: torch.Tensor | None = None) -> torch.Tensor:
@@ -298,7 +285,7 @@ class InpaintGeneratorMI355:
             local_prop = self.propagate_windows(st, [nb])[0]
         feat[:lt] = local_prop
         if refs:
-            feat[lt:] = st.enc[torch.tensor(refs, device=dev)]
+            torch.index_select(st.enc, 0, ops.device_ints(refs, dev), out=feat[lt:])
         fh, fw = token_grid(h, w)
         tok = torch.empty(t, fh, fw, 512, device=dev, dtype=F16)
         ops.conv2d(self.ss, [feat], tok)

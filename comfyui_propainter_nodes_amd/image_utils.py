@@ -86,20 +86,28 @@ def prepare_frames_and_masks(frames_u8: np.ndarray, mask: torch.Tensor, config: 
     return frames, flow_masks, masks_dilated
 
 
-def extrapolation(frames_u8: np.ndarray, config: ImageOutpaintConfig):
-    """Outpaint canvas + static border masks (:200-252)."""
-    frames = resize_frames(frames_u8, config.process_size)
-    T, rh, rw, _ = frames.shape
+def outpaint_geometry(config: ImageOutpaintConfig):
+    """-> ((pw, ph), (hs, ws), flow_mask u8 [ph,pw], mask u8 [ph,pw]): canvas size, frame offset and the two static
+    border masks of extrapolation (:200-252)."""
+    rw, rh = config.process_size
     pw, ph = config.outpaint_size
     ws, hs = int((pw - rw) / 2), int((ph - rh) / 2)
-    canvas = np.zeros((T, ph, pw, 3), dtype=np.uint8)
-    canvas[:, hs:hs + rh, ws:ws + rw] = frames
     dh = 4 if hs > 10 else 0
     dw = 4 if ws > 10 else 0
     mask = np.ones((ph, pw), dtype=np.uint8)
     mask[hs + dh:hs + rh - dh, ws + dw:ws + rw - dw] = 0
     flow_mask = mask.copy()
     mask[hs:hs + rh, ws:ws + rw] = 0
+    return (pw, ph), (hs, ws), flow_mask, mask
+
+
+def extrapolation(frames_u8: np.ndarray, config: ImageOutpaintConfig):
+    """Outpaint canvas + static border masks (:200-252), host path."""
+    frames = resize_frames(frames_u8, config.process_size)
+    T, rh, rw, _ = frames.shape
+    (pw, ph), (hs, ws), flow_mask, mask = outpaint_geometry(config)
+    canvas = np.zeros((T, ph, pw, 3), dtype=np.uint8)
+    canvas[:, hs:hs + rh, ws:ws + rw] = frames
     return canvas, np.repeat(flow_mask[None], T, 0), np.repeat(mask[None], T, 0)
 
 

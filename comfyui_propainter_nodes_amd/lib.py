@@ -5,8 +5,8 @@ sizes are cross-checked against `pp_struct_size()` at load time, so the Python s
 never silently drift from the C side.
 
 The product path loads ONLY the gfx950 library and raises loudly when it is missing.
-`load_emulator()` exists for the CPU test-suite: it loads the x86 emulation build of the very
-same kernel sources (tests/emu/), which is test infrastructure and never used by the nodes.
+(`Library.is_emulator` marks a library that takes host pointers: the CPU test-suite installs an x86
+emulation build of the same kernel sources from tests/emu/loader.py; nothing here loads it.)
 """
 from __future__ import annotations
 
@@ -18,7 +18,6 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 HEADER = ROOT / "include" / "propainter_mi355.h"
 HIP_LIB = PKG / "libpropainter_mi355.so"
-EMU_LIB = ROOT / "tests" / "emu" / "libpropainter_emu.so"
 
 _CT = {
     "int32_t": ctypes.c_int32,
@@ -127,13 +126,6 @@ def load() -> Library:
     global _lib
     if _lib is None:
         _lib = Library(HIP_LIB, is_emulator=False)
-    return _lib
-
-
-def load_emulator() -> Library:
-    """TESTS ONLY: route the C ABI to the x86 kernel emulator (tests/emu)."""
-    global _lib
-    _lib = Library(EMU_LIB, is_emulator=True)
     return _lib
 
 

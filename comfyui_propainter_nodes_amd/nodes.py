@@ -5,14 +5,20 @@ on the MI355X through libpropainter_mi355.
 """
 from __future__ import annotations
 
+import os
+import time
+
+import numpy as np
 import torch
 
+from . import ops
 from .image_utils import (
     ImageConfig,
     ImageOutpaintConfig,
     extrapolation,
     handle_output,
     image_to_uint8_frames,
+    outpaint_geometry,
     prepare_frames_and_masks,
 )
 from .pipeline import ProPainterConfig, initialize_models, run_inpainting
@@ -56,12 +62,61 @@ _COMMON_INPUTS = {
 }
 
 
-def _finish(models, frames_u8, flow_masks, masks_dilated, config):
-    composed = run_inpainting(models, frames_u8, flow_masks, masks_dilated, config)
-    dev = config.device
-    fm = torch.from_numpy(flow_masks).float().to(dev)
-    md = torch.from_numpy(masks_dilated).float().to(dev)
-    return handle_output(composed, fm, md)
+class _Timer:
+    """Stage wall-clock of one node call (PP_TIMING=1, or `LAST_TIMING` read by bench.py)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.on = os.environ.get("PP_TIMING") == "1" or _Timer.collect
+        self.marks = [("start", time.perf_counter())]
+
+    collect = False
+    last: dict = {}
+
+    def mark(self, name: str) -> None:
+        if self.on:
+            torch.cuda.synchronize(self.device)
+            self.marks.append((name, time.perf_counter()))
+
+    def done(self) -> None:
+        if self.on:
+            _Timer.last = {b[0]: round((b[1] - a[1]) * 1e3, 2) for a, b in zip(self.marks, self.marks[1:])}
+            if os.environ.get("PP_TIMING") == "1":
+                print("[pp] node ms: " + ", ".join(f"{k} {v}" for k, v in _Timer.last.items()), flush=True)
+
+
+def _device_io_ok(image: torch.Tensor, process_size, input_size, mask: torch.Tensor | None = None) -> bool:
+    """The device-side byte plumbing covers fp32 IMAGE / MASK inputs that need no resize; everything else (PIL bicubic
+    resize, exotic dtypes) takes the host path of image_utils.py, which is the reference's own."""
+    if os.environ.get("PP_HOST_IO") == "1":
+        return False
+    if tuple(process_size) != tuple(input_size) or image.dtype != torch.float32:
+        return False
+    return mask is None or mask.dtype == torch.float32
+
+
+def _expand_masks(m: torch.Tensor, T: int) -> torch.Tensor:
+    return m.expand(T, -1, -1).contiguous() if m.shape[0] == 1 and T != 1 else m
+
+
+def _output(comp_u8: torch.Tensor, fm_u8: torch.Tensor, md_u8: torch.Tensor):
+    """handle_output (image_utils.py:276-290): IMAGE fp32 k/255 on the host, the two masks fp32 on the device."""
+    images = ops.image_from_u8(comp_u8).cpu()
+    return images, fm_u8.float().squeeze(), md_u8.float().squeeze()
+
+
+TRACE: dict | None = None  # debugging / test aid: when a dict, the next node call leaves its stage tensors in it
+
+
+def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer):
+    if TRACE is not None:
+        TRACE.update(frames_u8=fr_u8, flow_masks=fm, masks_dilated=md)
+    comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32)
+    tm.mark("pipeline")
+    out = _output(comp, fm, md)
+    tm.mark("output(u8->float, D2H)")
+    tm.done()
+    return out
 
 
 class ProPainterInpaint:
@@ -92,16 +147,26 @@ class ProPainterInpaint:
                               raft_iter: int, fp16: str) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         check_inputs(image, mask)
         device = get_torch_device()
-        frames_u8 = image_to_uint8_frames(image)
+        tm = _Timer(device)
         video_length = image.size(dim=0)
-        input_size = (frames_u8.shape[2], frames_u8.shape[1])
+        input_size = (image.size(dim=2), image.size(dim=1))
         image_config = ImageConfig(width, height, mask_dilates, flow_mask_dilates, input_size, video_length)
         config = ProPainterConfig(ref_stride, neighbor_length, subvideo_length, raft_iter, fp16, video_length, device,
                                   image_config.process_size)
-        frames_u8, flow_masks, masks_dilated = prepare_frames_and_masks(frames_u8, mask, image_config)
         models = initialize_models(device, config.fp16)
+        if _device_io_ok(image, image_config.process_size, input_size, mask):
+            # one H2D of the fp32 IMAGE / MASK; uint8 conversion, [-1,1] scaling and mask dilation on the device
+            fr_u8, fr_f32 = ops.frames_from_image(image.detach().to(device).contiguous())
+            m = mask.detach().to(device).contiguous()
+            fm = _expand_masks(ops.mask_dilate(m, flow_mask_dilates), video_length)
+            md = _expand_masks(ops.mask_dilate(m, mask_dilates), video_length)
+        else:
+            frames_u8, flow_masks, masks_dilated = prepare_frames_and_masks(image_to_uint8_frames(image), mask, image_config)
+            fr_u8, fr_f32 = torch.from_numpy(frames_u8).to(device), None
+            fm, md = torch.from_numpy(flow_masks).to(device), torch.from_numpy(masks_dilated).to(device)
+        tm.mark("input(H2D, u8, masks)")
         print(f"\nProcessing  {config.video_length} frames...")
-        return _finish(models, frames_u8, flow_masks, masks_dilated, config)
+        return _run(models, config, fr_u8, fr_f32, fm, md, tm)
 
 
 class ProPainterOutpaint:
@@ -132,17 +197,27 @@ class ProPainterOutpaint:
                                mask_dilates: int, flow_mask_dilates: int, ref_stride: int, neighbor_length: int,
                                subvideo_length: int, raft_iter: int, fp16: str) -> tuple[torch.Tensor, torch.Tensor, int, int]:
         device = get_torch_device()
-        frames_u8 = image_to_uint8_frames(image)
+        tm = _Timer(device)
         video_length = image.size(dim=0)
-        input_size = (frames_u8.shape[2], frames_u8.shape[1])
+        input_size = (image.size(dim=2), image.size(dim=1))
         image_config = ImageOutpaintConfig(width, height, mask_dilates, flow_mask_dilates, input_size, video_length,
                                            width_scale, height_scale)
         config = ProPainterConfig(ref_stride, neighbor_length, subvideo_length, raft_iter, fp16, video_length, device,
                                   image_config.outpaint_size)
-        frames_u8, flow_masks, masks_dilated = extrapolation(frames_u8, image_config)
         models = initialize_models(device, config.fp16)
+        if _device_io_ok(image, image_config.process_size, input_size):
+            # outpaint fast path: the canvas is filled on the device, the two border masks are one static plane each
+            (pw, ph), (hs, ws), flow_mask, mask = outpaint_geometry(image_config)
+            fr_u8, fr_f32 = ops.frames_from_image(image.detach().to(device).contiguous(), (ph, pw), (hs, ws))
+            fm = _expand_masks(torch.from_numpy(flow_mask[None]).to(device), video_length)
+            md = _expand_masks(torch.from_numpy(mask[None]).to(device), video_length)
+        else:
+            frames_u8, flow_masks, masks_dilated = extrapolation(image_to_uint8_frames(image), image_config)
+            fr_u8, fr_f32 = torch.from_numpy(frames_u8).to(device), None
+            fm, md = torch.from_numpy(flow_masks).to(device), torch.from_numpy(masks_dilated).to(device)
+        tm.mark("input(H2D, u8, masks)")
         print(f"\nProcessing  {config.video_length} frames...")
-        output_frames, output_masks, _ = _finish(models, frames_u8, flow_masks, masks_dilated, config)
+        output_frames, output_masks, _ = _run(models, config, fr_u8, fr_f32, fm, md, tm)
         output_width, output_height = config.process_size
         return output_frames, output_masks, output_width, output_height
 

@@ -65,6 +65,21 @@ class ConvProfile:
 CONV_PROFILE: ConvProfile | None = None
 
 
+_INT_CACHE: dict = {}
+
+
+def device_ints(values, device, dtype: torch.dtype = torch.int64) -> torch.Tensor:
+    """A small integer index tensor on the device, cached by value (window / reference frame ids recur every clip,
+    so the steady state issues no pageable H2D copies for them)."""
+    key = (tuple(values), str(device), dtype)
+    t = _INT_CACHE.get(key)
+    if t is None:
+        if len(_INT_CACHE) > 4096:
+            _INT_CACHE.clear()
+        t = _INT_CACHE[key] = torch.tensor(list(values), dtype=dtype, device=device)
+    return t
+
+
 def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return PP_F32
@@ -663,3 +678,98 @@ def compose_u8(pred: torch.Tensor, frame_ids: torch.Tensor, first: torch.Tensor,
     P.L, P.H, P.W = l, h, w
     _call("pp_compose_u8", comp_u8, P)
     return comp_u8
+
+
+# --------------------------------------------------------------------------------------------
+# device-side pre / post-processing (the node's byte plumbing)
+# --------------------------------------------------------------------------------------------
+def frames_from_image(image: torch.Tensor, canvas_hw: tuple[int, int] | None = None, offset: tuple[int, int] = (0, 0),
+                      want_f32: bool = True):
+    """IMAGE fp32 [T,H,W,3] on the device -> (uint8 frames [T,Ho,Wo,3], fp32 frames in [-1,1] or None); with a
+    canvas the frames are placed at `offset` = (oy, ox) inside zeros (the outpaint canvas)."""
+    check_device(image)
+    if image.dtype != torch.float32 or image.dim() != 4 or image.shape[3] != 3 or not image.is_contiguous():
+        raise ValueError("frames_from_image: expected a dense fp32 [T,H,W,3] image")
+    t, h, w, _ = image.shape
+    ho, wo = canvas_hw or (h, w)
+    u8 = torch.empty(t, ho, wo, 3, dtype=torch.uint8, device=image.device)
+    f32 = torch.empty(t, ho, wo, 3, dtype=torch.float32, device=image.device) if want_f32 else None
+    P = _lib.STRUCTS["pp_frames_from_image_params"]()
+    P.image, P.out_u8 = image.data_ptr(), u8.data_ptr()
+    if f32 is not None:
+        P.out_f32 = f32.data_ptr()
+    P.T, P.H, P.W, P.Ho, P.Wo, P.oy, P.ox = t, h, w, ho, wo, offset[0], offset[1]
+    _call("pp_frames_from_image", u8, P)
+    return u8, f32
+
+
+def frames_from_u8(frames_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 frames [T,H,W,3] on the device -> fp32 frames in [-1,1]: (u8/255)*2-1 (image_utils.py:178-191)."""
+    check_device(frames_u8)
+    if frames_u8.dtype != torch.uint8 or not frames_u8.is_contiguous() or frames_u8.dim() != 4:
+        raise ValueError("frames_from_u8: expected dense uint8 [T,H,W,3] frames")
+    t, h, w, _ = frames_u8.shape
+    f32 = torch.empty(t, h, w, 3, dtype=torch.float32, device=frames_u8.device)
+    P = _lib.STRUCTS["pp_frames_from_image_params"]()
+    P.in_u8, P.out_u8, P.out_f32 = frames_u8.data_ptr(), frames_u8.data_ptr(), f32.data_ptr()
+    P.T, P.H, P.W, P.Ho, P.Wo = t, h, w, h, w
+    _call("pp_frames_from_image", f32, P)
+    return f32
+
+
+def image_from_u8(u8: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """uint8 tensor -> fp32 k/255 of the same shape (handle_output, image_utils.py:276-290)."""
+    check_device(u8, out)
+    if u8.dtype != torch.uint8 or not u8.is_contiguous() or u8.numel() % 4:
+        raise ValueError("image_from_u8: expected a dense uint8 tensor with a multiple of 4 elements")
+    if out is None:
+        out = torch.empty(u8.shape, dtype=torch.float32, device=u8.device)
+    P = _lib.STRUCTS["pp_image_from_u8_params"]()
+    setattr(P, "in", u8.data_ptr())
+    P.out, P.total = out.data_ptr(), u8.numel()
+    _call("pp_image_from_u8", out, P)
+    return out
+
+
+def mask_dilate(mask: torch.Tensor, iterations: int) -> torch.Tensor:
+    """MASK fp32 (ComfyUI) or uint8 [N,H,W] on the device -> uint8 {0,1} [N,H,W] (read_masks, image_utils.py:142-175)."""
+    check_device(mask)
+    if mask.dim() != 3 or not mask.is_contiguous() or mask.dtype not in (torch.float32, torch.uint8):
+        raise ValueError("mask_dilate: expected a dense fp32 / uint8 [N,H,W] mask")
+    n, h, w = mask.shape
+    out = torch.empty(n, h, w, dtype=torch.uint8, device=mask.device)
+    scratch = torch.empty(n, h, w, dtype=torch.uint8, device=mask.device)
+    P = _lib.STRUCTS["pp_mask_dilate_params"]()
+    P.dtype, P.iterations = dtype_code(mask.dtype), int(iterations)
+    setattr(P, "in", mask.data_ptr())
+    P.out, P.scratch, P.N, P.H, P.W = out.data_ptr(), scratch.data_ptr(), n, h, w
+    _call("pp_mask_dilate", out, P)
+    return out
+
+
+def clip_masks(m_in: torch.Tensor, m_upd: torch.Tensor, fh: int, fw: int):
+    """u8 masks [T,H,W] -> (maskpair f16 [T,H/4,W/4,8], tokmask u8 [T,fh,fw]) (propainter.py:409-428)."""
+    check_device(m_in, m_upd)
+    t, h, w = m_in.shape
+    if not (m_in.is_contiguous() and m_upd.is_contiguous()) or m_in.dtype != torch.uint8 or m_upd.dtype != torch.uint8:
+        raise ValueError("clip_masks: expected dense uint8 masks")
+    maskpair = torch.empty(t, h // 4, w // 4, 8, dtype=torch.float16, device=m_in.device)
+    tok = torch.empty(t, fh, fw, dtype=torch.uint8, device=m_in.device)
+    P = _lib.STRUCTS["pp_clip_masks_params"]()
+    P.m_in, P.m_upd, P.maskpair, P.tokmask = m_in.data_ptr(), m_upd.data_ptr(), maskpair.data_ptr(), tok.data_ptr()
+    P.T, P.H, P.W, P.fh, P.fw = t, h, w, fh, fw
+    _call("pp_clip_masks", tok, P)
+    return maskpair, tok
+
+
+def window_flags(tokmask: torch.Tensor, g0: int, lt: int, window: tuple[int, int]) -> torch.Tensor:
+    """tokmask u8 [T,fh,fw] -> i32 [nwin] 'window is masked' flags for local frames [g0, g0+lt) (sparse_transformer.py:321-326)."""
+    check_device(tokmask)
+    t, fh, fw = tokmask.shape
+    nwin = -(-fh // window[0]) * -(-fw // window[1])
+    flags = torch.empty(nwin, dtype=torch.int32, device=tokmask.device)
+    P = _lib.STRUCTS["pp_window_flags_params"]()
+    P.tokmask, P.flags = tokmask.data_ptr(), flags.data_ptr()
+    P.T, P.fh, P.fw, P.g0, P.lt, P.wh, P.ww = t, fh, fw, g0, lt, window[0], window[1]
+    _call("pp_window_flags", flags, P)
+    return flags

@@ -75,15 +75,49 @@ class Models:
     provenance: str = ""
 
 
-_MODEL_CACHE: dict[str, Models] = {}
+_MODEL_CACHE: dict[tuple, Models] = {}
+_WARNED: set[str] = set()
+
+
+def _warn_once(msg: str) -> None:
+    if msg not in _WARNED:
+        _WARNED.add(msg)
+        print(f"[ProPainter-MI355X] WARNING: {msg}", flush=True)
+
+
+def drop_model_cache() -> None:
+    """Release the cached, repacked networks (e.g. from a ComfyUI 'unload models' hook)."""
+    _MODEL_CACHE.clear()
 
 
 def initialize_models(device: torch.device, use_half: str = "enable", seed: int = 0) -> Models:
-    """Load + repack the three networks once per process and device (the reference reloads all
-    checkpoints on every node execution, utils/model_utils.py:49-59).  Pretrained checkpoints are
-    read from `weights/` when present, otherwise seeded synthetic weights are used (no network)."""
-    key = str(device)
+    """Load + repack the three networks once per process (the reference reloads all checkpoints on every node
+    execution, utils/model_utils.py:49-59).  The cache is keyed on the device, the precision mode and the identity of
+    the checkpoint files (path, size, mtime) so that swapping files in `weights/` is picked up.
+
+    Checkpoints are read from `weights/` (the reference downloads them there, utils/download_utils.py; there is no
+    network access here).  When they are missing the node FAILS, as a user would otherwise get plausible-looking
+    garbage; seeded synthetic weights are an explicit opt-in for benchmarks and tests
+    (PP_ALLOW_SYNTHETIC_WEIGHTS=1)."""
+    if use_half == "disable":
+        _warn_once("fp16='disable': RAFT runs on fp32 tensors as in the reference; flow completion and the generator keep "
+                   "f16 storage with fp32 accumulation / statistics / coordinates in this build (>= 60 dB against the "
+                   "fp32 reference on the parity fixtures) - there is no fp32-storage mode for those two networks yet")
+    if weights.weights_available():
+        ident = tuple((f, (weights.WEIGHT_DIR / f).stat().st_size, (weights.WEIGHT_DIR / f).stat().st_mtime_ns)
+                      for f in weights.FILES.values())
+    elif os.environ.get("PP_ALLOW_SYNTHETIC_WEIGHTS") == "1":
+        ident = ("synthetic", seed)
+        _warn_once(f"no checkpoints in {weights.WEIGHT_DIR}: running on SYNTHETIC weights (seed {seed}); the output is "
+                   "meaningless as an inpainting result (PP_ALLOW_SYNTHETIC_WEIGHTS=1 is set)")
+    else:
+        raise FileNotFoundError(
+            f"ProPainter checkpoints not found in {weights.WEIGHT_DIR}: place {', '.join(weights.FILES.values())} "
+            f"(release {weights.RELEASE_URL}) there. Set PP_ALLOW_SYNTHETIC_WEIGHTS=1 only for benchmarks / tests.")
+    key = (str(device), ops.f32_split_enabled(), ident)
     if key not in _MODEL_CACHE:
+        if len(_MODEL_CACHE) >= 2:  # a stale entry pins three networks in HBM: keep at most the previous one
+            _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))
         sds, prov = weights.get_state_dicts(seed)
         _MODEL_CACHE[key] = Models(RaftFlow(sds["raft"], device), FlowCompleter(sds["rfc"], device),
                                    InpaintGeneratorMI355(sds["gen"], device), prov)
@@ -136,10 +170,36 @@ def image_propagation(frames: torch.Tensor, masks_u8: torch.Tensor, flows: torch
     return prop, upd
 
 
+_SCHED_CACHE: dict = {}
+
+
+def device_schedule(config: ProPainterConfig):
+    """The window schedule as host lists plus ONE device tensor holding, for every window, the global frame ids of
+    its local frames and their first-visit flags (the uint8 compose is order dependent, :283-307); cached per
+    (clip length, window parameters, device) so the steady state does no H2D copies for scheduling."""
+    key = (config.video_length, config.neighbor_length, config.ref_stride, config.subvideo_length, str(config.device))
+    hit = _SCHED_CACHE.get(key)
+    if hit is None:
+        schedule = window_schedule(config)
+        seen = [False] * config.video_length
+        rows, spans = [], []
+        for nb, _ in schedule:
+            spans.append((len(rows), len(rows) + len(nb)))
+            for i in nb:
+                rows.append((i, 0 if seen[i] else 1))
+                seen[i] = True
+        table = torch.tensor(rows, dtype=torch.int32).t().contiguous().to(config.device)  # [2, sum(l_t)]
+        if len(_SCHED_CACHE) > 16:
+            _SCHED_CACHE.clear()
+        hit = _SCHED_CACHE[key] = (schedule, spans, table)
+    return hit
+
+
 def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, config: ProPainterConfig,
-                   trace: dict | None = None, to_host: bool = True) -> torch.Tensor:
+                   trace: dict | None = None, to_host: bool = True, frames_f32: torch.Tensor | None = None) -> torch.Tensor:
     """uint8 arrays / tensors in ([T,H,W,3], [T,H,W], [T,H,W]) -> composed uint8 frames [T,H,W,3]
-    (CPU tensor, or left in HBM when `to_host` is False).
+    (CPU tensor, or left in HBM when `to_host` is False).  `frames_f32` = the fp32 [-1,1] frames when the caller
+    already produced them on the device (ops.frames_from_image).
 
     = process_inpainting (:314-341) + feature_propagation (:228-311) of the reference."""
     dev = config.device
@@ -153,11 +213,11 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
             print(f"[pp] {name} done", flush=True)
 
     mark("start")
-    fr_u8 = torch.as_tensor(frames_u8).to(dev)
+    fr_u8 = torch.as_tensor(frames_u8).to(dev).contiguous()
     fm = torch.as_tensor(flow_masks_u8).to(dev).contiguous()
     md = torch.as_tensor(masks_dilated_u8).to(dev).contiguous()
     T, H, W, _ = fr_u8.shape
-    frames = fr_u8.float().div(255) * 2 - 1  # to_tensors(): x/255*2-1 (image_utils.py:191)
+    frames = frames_f32 if frames_f32 is not None else ops.frames_from_u8(fr_u8)  # to_tensors(): x/255*2-1 (image_utils.py:191)
     gt = compute_flow(models.raft_model, frames, config)
     mark("raft")
     pred = complete_flow(models.flow_model, gt, fm, config.subvideo_length)
@@ -171,19 +231,15 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     st = gen.prepare_clip(packed, pred, md, upd)
     mark("encoder+clip_prep")
     comp = torch.zeros(T, H, W, 3, dtype=torch.uint8, device=dev)
-    seen = [False] * T
     if trace is not None:
         trace.update(gt_flows=gt, pred_flows=pred, updated_frames=updated, updated_masks=upd, pred_imgs=[])
-    schedule = window_schedule(config)
+    schedule, spans, table = device_schedule(config)
     props = gen.propagate_windows(st, [nb for nb, _ in schedule])
     mark("feature_propagation(all windows batched)")
     for wi, (nb, refs) in enumerate(schedule):
         out = gen.forward_window(st, nb, refs, local_prop=props[wi])
-        ids = torch.tensor(nb, dtype=torch.int32, device=dev)
-        first = torch.tensor([0 if seen[i] else 1 for i in nb], dtype=torch.int32, device=dev)
-        ops.compose_u8(out, ids, first, md, fr_u8, comp)
-        for i in nb:
-            seen[i] = True
+        a, b = spans[wi]
+        ops.compose_u8(out, table[0, a:b], table[1, a:b], md, fr_u8, comp)
         if trace is not None:
             trace["pred_imgs"].append(out[..., :3].float().cpu())
     mark("windows(transformer+decoder+compose)")

@@ -21,6 +21,7 @@ import torch
 
 PKG = Path(__file__).resolve().parent
 WEIGHT_DIR = PKG.parent / "weights"
+RELEASE_URL = "https://github.com/sczhou/ProPainter/releases/download/v0.1.0/"  # utils/model_utils.py:20
 FILES = {"raft": "raft-things.pth", "rfc": "recurrent_flow_completion.pth", "gen": "ProPainter.pth"}
 
 with open(PKG / "weights_spec.json") as _f:
@@ -99,12 +100,14 @@ def check_state_dict(net: str, sd: dict[str, torch.Tensor]) -> None:
             raise RuntimeError(f"{FILES[net]}: {k} has shape {list(sd[k].shape)}, expected {shp}")
 
 
-def weights_available(weight_dir: Path = WEIGHT_DIR) -> bool:
+def weights_available(weight_dir: Path | None = None) -> bool:
+    weight_dir = weight_dir or WEIGHT_DIR
     return all((weight_dir / f).exists() for f in FILES.values())
 
 
-def load_state_dicts(weight_dir: Path = WEIGHT_DIR) -> dict[str, dict[str, torch.Tensor]]:
+def load_state_dicts(weight_dir: Path | None = None) -> dict[str, dict[str, torch.Tensor]]:
     """Load the three pretrained checkpoints from `weights/` (no download: there is no network)."""
+    weight_dir = weight_dir or WEIGHT_DIR
     out = {}
     for net, fname in FILES.items():
         path = weight_dir / fname

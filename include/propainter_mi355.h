@@ -459,6 +459,74 @@ typedef struct {
 } pp_compose_u8_params;
 int32_t pp_compose_u8(void* stream, const pp_compose_u8_params* p);
 
+/* ------------------------------------------------------------------------------------
+ * Device-side pre / post-processing (the reference does this on the host with
+ * numpy / PIL / scipy and marks it TODO at propainter_nodes.py:110,248).  All bit-exact.
+ *
+ * pp_frames_from_image -- convert_image_to_frames (utils/image_utils.py:106-116) + to_tensors
+ * and "*2-1" (:178-191) + the outpaint canvas of extrapolation (:200-252):
+ *   out_u8 [T][Ho][Wo][3] = trunc(clip(image*255, 0, 255)) placed at (oy, ox), 0 elsewhere;
+ *   out_f32 (optional)    = (out_u8 / 255) * 2 - 1.
+ * image: fp32 [T][H][W][3] (ComfyUI IMAGE).  With image == NULL the uint8 frames in_u8
+ * [T][Ho][Wo][3] (resized on the host by PIL) are only converted to out_f32.
+ * pp_image_from_u8 -- handle_output (:276-290): out fp32 = float(k) / 255; total % 4 == 0.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* image;
+  const void* in_u8;
+  void* out_u8;
+  void* out_f32;
+  int64_t T, H, W, Ho, Wo, oy, ox;
+} pp_frames_from_image_params;
+int32_t pp_frames_from_image(void* stream, const pp_frames_from_image_params* p);
+
+typedef struct {
+  const void* in;
+  void* out;
+  int64_t total;
+} pp_image_from_u8_params;
+int32_t pp_image_from_u8(void* stream, const pp_image_from_u8_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_mask_dilate -- read_masks (utils/image_utils.py:142-175): convert_mask_to_frames'
+ * u8 = trunc(clamp(m*255, 0, 255)) for a float MASK (dtype PP_F32; PP_U8 input is used as is),
+ * then scipy.ndimage.binary_dilation(arr, iterations) = "a non-zero pixel within L1 distance
+ * <= iterations" (border 0); iterations == 0 is binary_mask (arr > 0.1).  in [N][H][W],
+ * out u8 {0,1} [N][H][W], scratch u8 [N][H][W] (caller owned).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;
+  int32_t iterations;
+  const void* in;
+  void* out;
+  void* scratch;
+  int64_t N, H, W;
+} pp_mask_dilate_params;
+int32_t pp_mask_dilate(void* stream, const pp_mask_dilate_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_clip_masks -- the binary planes InpaintGenerator.forward derives from the masks
+ * (propainter.py:409-428): maskpair f16 [T][H/4][W/4][8] = (nearest x1/4 of m_in, of m_upd, 0..)
+ * and tokmask u8 [T][fh][fw] = MaxPool2d(7, 3, 3) of the 1/4-res m_in plane.
+ * pp_window_flags -- sparse_transformer.py:321-326: flags i32 [ceil(fh/wh)*ceil(fw/ww)], 1 iff any
+ * token mask of frames [g0, g0+lt) falls inside the window.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* m_in;  /* u8 [T][H][W] */
+  const void* m_upd; /* u8 [T][H][W] */
+  void* maskpair;
+  void* tokmask;
+  int64_t T, H, W, fh, fw;
+} pp_clip_masks_params;
+int32_t pp_clip_masks(void* stream, const pp_clip_masks_params* p);
+
+typedef struct {
+  const void* tokmask; /* u8 [T][fh][fw] */
+  void* flags;
+  int64_t T, fh, fw, g0, lt, wh, ww;
+} pp_window_flags_params;
+int32_t pp_window_flags(void* stream, const pp_window_flags_params* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,8 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
+if str(ROOT / "tests" / "emu") not in sys.path:
+    sys.path.insert(0, str(ROOT / "tests" / "emu"))
 
 
 def pytest_configure(config):
@@ -25,10 +27,10 @@ def pytest_configure(config):
 @pytest.fixture()
 def emu_lib():
     """Build (if needed) and load the x86 emulation of the kernel sources. TEST ONLY."""
-    from comfyui_propainter_nodes_amd import build, lib
+    import emu_loader
+    from comfyui_propainter_nodes_amd import lib
 
-    build.build_emu()
-    L = lib.load_emulator()
+    L = emu_loader.load_emulator()
     yield L
     lib.unload()
 
@@ -56,8 +58,9 @@ def backend(request, monkeypatch):
     from comfyui_propainter_nodes_amd import build, lib
 
     if request.param == "emu":
-        build.build_emu()
-        lib.load_emulator()
+        import emu_loader
+
+        emu_loader.load_emulator()
         yield torch.device("cpu")
         lib.unload()
     else:

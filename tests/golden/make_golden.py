@@ -180,6 +180,111 @@ def host_cases():
     print("host_cases written")
 
 
+def _rel(a, b):
+    return rel_err(a, b)
+
+
+def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_length, ref_stride, subvideo_length,
+                  mask_dilates=5, flow_mask_dilates=8, width_scale=1.2, height_scale=1.0, seed=0, flow_stride=4,
+                  save=True, check_oracle=True):
+    """BASELINE-config fixtures minted THROUGH THE REFERENCE'S NODE METHODS (propainter_nodes.py:93-154 / :231-310),
+    fp16 "disable" on CPU, with the stage tensors captured on the way.  Stored compactly (the inputs are regenerable
+    from the seed): RAFT flows as f32 on a 2*`flow_stride` sub-grid, completed flows as f16 on a `flow_stride` sub-grid, updated masks bit-packed, the node's IMAGE output only
+    where masks_dilated == 1 (elsewhere it must equal the prepared input frames bit for bit, which the test checks
+    against its own host plumbing), the two mask outputs bit-packed."""
+    import time
+
+    sds = weights.synth_state_dicts(seed)
+    ref, models = build_reference_models(sds)
+    import reference.propainter_inference as PI
+    import reference.propainter_nodes as RN
+
+    cap = {}
+    orig_cf, orig_pi, orig_init = PI.compute_flow, RN.process_inpainting, RN.initialize_models
+
+    def cf(raft_model, frames, config):
+        out = orig_cf(raft_model, frames, config)
+        cap["gt"] = out
+        cap["frames_t"] = frames
+        return out
+
+    def pi(models_, frames, flow_masks, masks_dilated, config):
+        out = PI.process_inpainting(models_, frames, flow_masks, masks_dilated, config)
+        cap["uf"], cap["um"], cap["pred"] = out
+        cap["fm_t"], cap["md_t"] = flow_masks, masks_dilated
+        return out
+
+    PI.compute_flow = cf
+    RN.process_inpainting = pi
+    RN.initialize_models = lambda device, fp16: models
+    image, mask = synth.synthetic_clip(T, H, W)
+    common = dict(mask_dilates=mask_dilates, flow_mask_dilates=flow_mask_dilates, ref_stride=ref_stride,
+                  neighbor_length=neighbor_length, subvideo_length=subvideo_length, raft_iter=raft_iter, fp16="disable")
+    t0 = time.time()
+    try:
+        if kind == "inpaint":
+            out_img, out_a, out_b = RN.ProPainterInpaint().propainter_inpainting(image, mask, width, height, **common)
+            extra = {}
+        else:
+            out_img, out_a, ow, oh = RN.ProPainterOutpaint().propainter_outpainting(image, width, height, width_scale,
+                                                                                    height_scale, **common)
+            out_b = cap["md_t"].squeeze()
+            extra = {"out_wh": np.array([ow, oh])}
+    finally:
+        PI.compute_flow, RN.process_inpainting, RN.initialize_models = orig_cf, orig_pi, orig_init
+    dt = time.time() - t0
+    md = cap["md_t"][0, :, 0].numpy().astype(np.uint8)          # [T,h,w]
+    fm = cap["fm_t"][0, :, 0].numpy().astype(np.uint8)
+    out_u8 = (out_img.numpy() * 255 + 0.5).astype(np.uint8)     # [T,h,w,3]
+    h, w = md.shape[1:]
+    print(f"{name}: reference node call {dt:.1f} s for {T} frames at {w}x{h} ({T / dt:.3f} frames/s, "
+          f"{torch.get_num_threads()} threads)")
+    if check_oracle:
+        frames_u8 = ((cap["frames_t"][0].permute(0, 2, 3, 1) + 1) / 2 * 255 + 0.5).numpy().astype(np.uint8)
+        ocomp, tr = OP.run(sds, cap["frames_t"], cap["fm_t"], cap["md_t"], [f for f in frames_u8], raft_iter=raft_iter,
+                           neighbor_length=neighbor_length, ref_stride=ref_stride, subvideo_length=subvideo_length,
+                           return_trace=True)
+        ocomp = np.stack(ocomp, 0)
+        print("   oracle pin:", {
+            "gt_flow": f"{max(_rel(tr['gt_flows'][i], cap['gt'][i]) for i in (0, 1)):.2e}",
+            "pred_flow": f"{max(_rel(tr['pred_flows'][i], cap['pred'][i]) for i in (0, 1)):.2e}",
+            "updated_frames": f"{_rel(tr['updated_frames'], cap['uf']):.2e}",
+            "updated_masks": f"{_rel(tr['updated_masks'], cap['um']):.2e}",
+            "composed_maxdiff_u8": int(np.abs(ocomp.astype(np.int32) - out_u8.astype(np.int32)).max()),
+            "composed_frac_diff": float((ocomp != out_u8).mean())})
+    if save:
+        s = flow_stride
+        sel = md.astype(bool)
+        np.savez_compressed(
+            HERE / f"{name}.npz",
+            kind=np.array(kind), params_json=np.array(__import__("json").dumps(dict(
+                T=T, H=H, W=W, width=width, height=height, width_scale=width_scale, height_scale=height_scale, seed=seed,
+                flow_stride=s, **common))),
+            gt_flow=np.stack([cap["gt"][i][0, :, :, ::2 * s, ::2 * s].numpy() for i in (0, 1)], 0).astype(np.float32),
+            pred_flow=np.stack([cap["pred"][i][0, :, :, ::s, ::s].numpy() for i in (0, 1)], 0).astype(np.float16),
+            updated_masks=np.packbits(cap["um"][0, :, 0].numpy().astype(np.uint8)),
+            out_masked=out_u8[sel],                                    # [n_masked_pixels, 3] in (t, y, x) order
+            out_crc=np.array([int(out_u8.astype(np.uint64).sum())]),
+            flow_masks=np.packbits(fm), masks_dilated=np.packbits(md), hw=np.array([h, w]),
+            out_a=np.packbits((out_a.numpy() > 0.5).astype(np.uint8)), out_a_shape=np.array(out_a.shape),
+            out_b=np.packbits((out_b.numpy() > 0.5).astype(np.uint8)), out_b_shape=np.array(out_b.shape),
+            ref_seconds=np.array([dt]), ref_threads=np.array([torch.get_num_threads()]), **extra)
+        print("   written", (HERE / f"{name}.npz").stat().st_size // 1024, "KiB")
+
+
+NODE_CASES = {
+    # BASELINE.json configs[0]: 16-frame 320x180 clip (-> 320x176: PIL bicubic resize of frames and mask), raft_iter 5
+    "cfg1_node": dict(kind="inpaint", T=16, H=180, W=320, width=320, height=180, raft_iter=5, neighbor_length=10,
+                      ref_stride=10, subvideo_length=80, flow_stride=2),
+    # configs[1] geometry (640x360, nl 10, rs 10, raft_iter 20) on a 24-frame truncation of the clip
+    "cfg2_24f_node": dict(kind="inpaint", T=24, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                          ref_stride=10, subvideo_length=80),
+    # configs[2] geometry: outpaint 640x360 -> 768x360 canvas (64-px borders), 12-frame truncation
+    "cfg3_12f_node": dict(kind="outpaint", T=12, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                          ref_stride=10, subvideo_length=80),
+}
+
+
 CASES = {
     # small end-to-end clip, global reference frames (T <= subvideo_length)
     "e2e_small": dict(T=6, H=128, W=144, raft_iter=3, neighbor_length=4, ref_stride=2, subvideo_length=80,
@@ -201,6 +306,9 @@ def main():
     for name, kw in CASES.items():
         if args.case in ("all", name):
             run_case(name, save=not args.no_save, **kw)
+    for name, kw in NODE_CASES.items():
+        if args.case in ("all", name):
+            run_node_case(name, save=not args.no_save, **kw)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,132 @@
+"""GPU parity at the BASELINE.json configurations, through the NODE METHODS (the drop-in boundary).
+
+Fixtures (tests/golden/cfg*_node.npz) were minted by running the reference's own node methods
+(propainter_nodes.py:93-154 / :231-310) on CPU fp32 with the seeded synthetic weights and the seeded synthetic clip
+(tests/golden/make_golden.py: run_node_case), capturing stage tensors on the way:
+  cfg1_node      BASELINE configs[0]: 16 frames 320x180 -> 320x176 (PIL bicubic resize path), raft_iter 5
+  cfg2_24f_node  configs[1] geometry: 640x360, nl 10, rs 10, raft_iter 20 (30x54 tokens, 6x6 windows), 24-frame truncation
+  cfg3_12f_node  configs[2] geometry: outpaint 640x360 -> 768x360, 12-frame truncation
+Tolerances = tests/test_e2e.py (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact):
+  RAFT flows 2e-3 px; completed flows 3e-2 px; updated masks <= 0.5 % differing pixels; final uint8 frames: exactly
+  the input outside the dilated mask, PSNR >= 40 dB and >= 99 % within 2 LSB inside it; node mask outputs bit-exact.
+A live-oracle case covers configs[4]'s geometry (1280x720, nl 20: 60x107 -> 60x108 token grid, 405 pooled keys)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from comfyui_propainter_nodes_amd import nodes, pipeline, synth
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def psnr(a, b, peak=255.0):
+    mse = float(((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean())
+    return 99.0 if mse == 0 else 10 * np.log10(peak * peak / mse)
+
+
+def _unpack(bits, shape):
+    n = int(np.prod(shape))
+    return np.unpackbits(bits)[:n].reshape(shape)
+
+
+@pytest.fixture()
+def synthetic_models(monkeypatch):
+    monkeypatch.setenv("PP_ALLOW_SYNTHETIC_WEIGHTS", "1")
+    pipeline.drop_model_cache()
+    yield
+    pipeline.drop_model_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cfg1_node", "cfg2_24f_node", "cfg3_12f_node"])
+def test_node_matches_reference_fixture(hip_lib, synthetic_models, case):
+    g = np.load(GOLD / f"{case}.npz")
+    P = json.loads(str(g["params_json"]))
+    kind = str(g["kind"])
+    image, mask = synth.synthetic_clip(P["T"], P["H"], P["W"])
+    common = {k: P[k] for k in ("mask_dilates", "flow_mask_dilates", "ref_stride", "neighbor_length", "subvideo_length",
+                                "raft_iter")}
+    nodes.TRACE = tr = {}
+    try:
+        if kind == "inpaint":
+            out_img, out_a, out_b = nodes.ProPainterInpaint().propainter_inpainting(image, mask, P["width"], P["height"],
+                                                                                    fp16="enable", **common)
+        else:
+            out_img, out_a, ow, oh = nodes.ProPainterOutpaint().propainter_outpainting(
+                image, P["width"], P["height"], P["width_scale"], P["height_scale"], fp16="enable", **common)
+            assert [ow, oh] == [int(v) for v in g["out_wh"]]
+            out_b = None
+    finally:
+        nodes.TRACE = None
+    h, w = [int(v) for v in g["hw"]]
+    T = P["T"]
+    assert out_img.dtype == torch.float32 and tuple(out_img.shape) == (T, h, w, 3) and not out_img.is_cuda
+    # ---- node mask outputs: bit-exact ------------------------------------------------------------------------------
+    md = _unpack(g["masks_dilated"], (T, h, w))
+    fm = _unpack(g["flow_masks"], (T, h, w))
+    assert np.array_equal(tr["flow_masks"].cpu().numpy(), fm) and np.array_equal(tr["masks_dilated"].cpu().numpy(), md)
+    assert tuple(out_a.shape) == tuple(int(v) for v in g["out_a_shape"])
+    assert np.array_equal((out_a.cpu().numpy() > 0.5).astype(np.uint8), _unpack(g["out_a"], tuple(out_a.shape)))
+    if out_b is not None:
+        assert np.array_equal((out_b.cpu().numpy() > 0.5).astype(np.uint8), _unpack(g["out_b"], tuple(out_b.shape)))
+    # ---- stage tensors ---------------------------------------------------------------------------------------------
+    s = P["flow_stride"]
+    gt = tr["gt_flows"].cpu()[:, :, ::2 * s, ::2 * s].permute(0, 1, 4, 2, 3).numpy()      # [2,T-1,2,h/2s,w/2s]
+    e_gt = float(np.abs(gt - g["gt_flow"]).max())
+    pf = tr["pred_flows"].cpu()[:, :, ::s, ::s].permute(0, 1, 4, 2, 3).numpy()
+    e_pf = float(np.abs(pf - g["pred_flow"].astype(np.float32)).max())
+    um = _unpack(g["updated_masks"], (T, h, w))
+    frac_m = float((tr["updated_masks"].cpu().numpy() != um).mean())
+    # ---- final frames ----------------------------------------------------------------------------------------------
+    out_u8 = (out_img.numpy() * 255 + 0.5).astype(np.uint8)
+    assert np.array_equal(out_u8.astype(np.float32) / 255.0, out_img.numpy())                # values are exactly k/255
+    sel = md.astype(bool)
+    frames_in = tr["frames_u8"].cpu().numpy()
+    assert np.array_equal(out_u8[~sel], frames_in[~sel])                                     # untouched outside the mask
+    got, want = out_u8[sel], g["out_masked"]
+    p = psnr(got, want)
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    frac2 = float((diff > 2).mean())
+    print(f"{case}: gt_flow {e_gt:.2e} px, pred_flow {e_pf:.2e} px, upd_mask_frac {frac_m:.2e}, masked-pixel PSNR {p:.1f} dB, "
+          f"max {int(diff.max())} LSB, frac>2LSB {frac2:.2e}")
+    assert e_gt < 2e-3
+    assert e_pf < 3e-2
+    assert frac_m < 5e-3
+    assert p >= 40.0 and frac2 < 1e-2
+
+
+@pytest.mark.gpu
+def test_cfg5_geometry_against_live_oracle(hip_lib):
+    """BASELINE configs[4] geometry on a short clip: 1280x720, neighbor_length 20, ref_stride 10 -> token grid 60x107
+    padded to 60x108, 12x12 windows, 405 pooled keys per frame; the CPU oracle runs beside it (raft_iter 2, 5 frames)."""
+    from comfyui_propainter_nodes_amd import image_utils, weights
+    from oracle import pipeline as OP
+
+    T, H, W = 5, 720, 1280
+    kw = dict(raft_iter=2, neighbor_length=20, ref_stride=10, subvideo_length=80)
+    image, mask = synth.synthetic_clip(T, H, W)
+    frames_u8 = image_utils.image_to_uint8_frames(image)
+    frames_u8, fm, md = image_utils.prepare_frames_and_masks(frames_u8, mask, image_utils.ImageConfig(W, H, 5, 8, (W, H), T))
+    sds = weights.synth_state_dicts(0)
+    dev = torch.device("cuda:0")
+    models = pipeline.models_from_state_dicts(sds, dev)
+    cfg = pipeline.ProPainterConfig(kw["ref_stride"], kw["neighbor_length"], kw["subvideo_length"], kw["raft_iter"], "enable",
+                                    T, dev, (W, H))
+    tr = {}
+    got = pipeline.run_inpainting(models, frames_u8, fm, md, cfg, trace=tr).numpy()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    frames = (torch.from_numpy(frames_u8).float().div(255) * 2 - 1).permute(0, 3, 1, 2)[None]
+    ref, otr = OP.run(sds, frames, torch.from_numpy(fm).float()[None, :, None], torch.from_numpy(md).float()[None, :, None],
+                      [f for f in frames_u8], return_trace=True, **kw)
+    ref = np.stack(ref, 0)
+    e_gt = max(float((tr["gt_flows"][i].cpu() - otr["gt_flows"][i][0].permute(0, 2, 3, 1)).abs().max()) for i in (0, 1))
+    e_pf = max(float((tr["pred_flows"][i].cpu() - otr["pred_flows"][i][0].permute(0, 2, 3, 1)).abs().max()) for i in (0, 1))
+    sel = md.astype(bool)
+    p = psnr(got[sel], ref[sel])
+    print(f"cfg5 geometry: gt_flow {e_gt:.2e} px, pred_flow {e_pf:.2e} px, masked-pixel PSNR {p:.1f} dB, "
+          f"max {int(np.abs(got.astype(int) - ref.astype(int)).max())} LSB")
+    assert np.array_equal(got[~sel], ref[~sel])
+    assert e_gt < 2e-3 and e_pf < 3e-2 and p >= 40.0

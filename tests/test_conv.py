@@ -273,11 +273,13 @@ if __name__ == "__main__":  # child process of test_conv2d_matches_torch
     from pathlib import Path
 
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-    from comfyui_propainter_nodes_amd import build, lib
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "emu"))
+    from comfyui_propainter_nodes_amd import lib
 
     if os.environ["PP_TEST_BACKEND"] == "emu":
-        build.build_emu()
-        lib.load_emulator()
+        import emu_loader
+
+        emu_loader.load_emulator()
         dev = torch.device("cpu")
     else:
         lib.load()

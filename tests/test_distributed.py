@@ -120,3 +120,55 @@ def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib):
         res = D.run_simulated(lambda r: D.GpuBackend(models, cfg), world, cfg, fr, fm, md)
         for r in range(world):
             assert torch.equal(res[r].cpu(), single), f"world {world} rank {r}"
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    """One REAL process per rank, the real MI355X backend, a real process group (gloo: both ranks share the one GPU
+    of the test box, tensors are staged through the host for the collectives)."""
+    import torch.distributed as dist
+
+    from comfyui_propainter_nodes_amd import lib, weights
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib.load()
+    g = np.load(GOLD / "e2e_chunked.npz")
+    T, H, W, iters, nl, rs, sv, _, _, seed = [int(v) for v in g["params"]]
+    dev = torch.device("cuda:0")
+    models = pipeline.models_from_state_dicts(weights.synth_state_dicts(seed), dev)
+    cfg = pipeline.ProPainterConfig(rs, nl, sv, iters, "enable", T, dev, (W, H))
+    fr, fm, md = (torch.from_numpy(g[k]).to(dev) for k in ("frames_u8", "flow_masks", "masks_dilated"))
+    res = D.run_distributed(D.GpuBackend(models, cfg), cfg, fr, fm, md)
+    torch.save(res.cpu(), Path(out_dir) / f"r{rank}.pt")
+    if rank == 0:
+        torch.save(pipeline.run_inpainting(models, fr, fm, md, cfg), Path(out_dir) / "single.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_processes_with_the_gpu_backend_match_single_process(hip_lib, tmp_path):
+    port = 29500 + (os.getpid() * 3 + 11) % 2000
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    single = torch.load(tmp_path / "single.pt")
+    for r in range(2):
+        assert torch.equal(torch.load(tmp_path / f"r{r}.pt"), single), f"rank {r}"
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks(hip_lib):
+    """`python bench.py --gpus 2` run bare launches two ranks under torch.distributed.run (gloo here: one GPU on the
+    test box; the driver's SCALE run uses RCCL, one rank per GPU) and prints one JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PP_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "40",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu"] == 40 and line["value"] > 0
