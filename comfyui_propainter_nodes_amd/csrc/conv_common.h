@@ -186,6 +186,15 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
   }
 }
 
+// PP_F32X2 low term of v given its high term h = f16_rtz(v): (v - h) * 2048, saturated to the f16 range.  The
+// remainder only reaches the limit for |v| >= 32752 (ulp(h) = 32: a remainder of 31.99 scales to 65515, which would
+// round to infinity): there the representation degrades gracefully (absolute error <= 0.016 up to |v| = 65504, and
+// v saturates at +-65536 beyond) instead of poisoning the accumulators with Inf - Inf.
+__device__ __forceinline__ float split_lo(float v, float h) {
+  const float r = (v - h) * 2048.f;
+  return fminf(fmaxf(r, -65504.f), 65504.f);
+}
+
 // one 16-byte f16 MFMA fragment from LDS (PP_ABLATE & 16: a register constant instead)
 __device__ __forceinline__ h8 lds_frag(const void* ptr) {
 #if PP_ABLATE & 16
@@ -201,25 +210,28 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
   // Small problems (the per-step convolutions of the two recurrences: M = 2*45*80 or 90*160 pixels) would
   // fill only a fraction of the 256 CUs with 128-pixel tiles: switch to 32-pixel tiles (4x the work-groups).
   const int64_t blocks128 = ((k.M + 127) / 128) * ((k.Cout + 127) / 128) * Z;
-  // PP_CONV_TILE=large|small pins the choice (tests cover both tile families).  Experiment (not a default yet):
-  // PP_CONV_TILE=xl uses 8-wave 256-channel x 128-pixel tiles when the problem is large
-  // (half the pixel-tile gather per flop); "xlforce" does so regardless of the problem size (tests).
+  // Defaults (each rule parity-checked and timed on the MI355X, profiles/r02_*): 8-wave 256-channel x 128-pixel tiles
+  // for large problems whose Cout pads to 256 as cheaply as to 128 (half the pixel-tile gather per flop: clip 642 ->
+  // 633 ms), 32-pixel tiles for the per-step convolutions of the recurrences and 16-pixel tiles when even those leave
+  // CUs idle (-> 627 ms).  PP_CONV_TILE pins one family for tests: large | small | xlforce | tiny | classic
+  // (classic = the r01 rules: no 8-wave and no 16-pixel tiles).
   static const int forced = [] {
     const char* e = getenv("PP_CONV_TILE");
     if (!e) return 0;
-    if (e[0] == 'x') return strcmp(e, "xlforce") == 0 ? 4 : 3;
-    if (e[0] == 't') return 5;  // "tiny": experiment, 16-pixel tiles for problems that leave CUs idle even with 32
+    if (e[0] == 'x') return strcmp(e, "xlforce") == 0 ? 4 : 0;
+    if (e[0] == 't') return 5;
+    if (e[0] == 'c') return 6;
     return e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
   }();
-  const bool small = forced == 2 || ((forced == 0 || forced == 3 || forced == 5) && blocks128 < 224);
+  const bool small = forced == 2 || ((forced == 0 || forced == 5 || forced == 6) && blocks128 < 224);
   // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would, and at most 1/8)
   const int waste256 = (k.Cout + 255) / 256 * 256 - k.Cout;
   const bool fits256 = (k.Cout + 255) / 256 * 256 == (k.Cout + 127) / 128 * 128 && waste256 * 8 <= k.Cout;
-  if (forced >= 3 && fits256 && (forced == 4 || blocks128 >= 1024))
+  if (fits256 && (forced == 4 || (forced == 0 && blocks128 >= 1024)))
     return F::template run<4, 2, 4, 4>(stream, k, Z);                                // 256 x 128, 8 waves
   if (k.Cout > 64) {
-    // experiment (PP_CONV_TILE=tiny): 16-pixel tiles when 32-pixel tiles still give at most ~1 work-group per CU
-    if (forced == 5 && blocks128 * 4 < 320) return F::template run<4, 1, 2, 1>(stream, k, Z);  // 128 x 16
+    // 16-pixel tiles when 32-pixel tiles still give at most ~1 work-group per CU
+    if ((forced == 5 || forced == 0) && blocks128 * 4 < 320) return F::template run<4, 1, 2, 1>(stream, k, Z);  // 128 x 16
     if (small) return F::template run<4, 1, 2, 2>(stream, k, Z);                     // 128 x  32
     // 96-wide tiles when they waste clearly fewer output channels than 128-wide ones (Cout 192, 576, ...)
     const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
@@ -241,5 +253,7 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
 
 // f32 convolution on the f16 matrix pipe (PP_F32X2): conv_split.hip
 int launch_split(void* stream, const ConvK& k, int Z);
+// ... and its halo-tile form for stride-1 multi-tap convolutions (conv_halo.hip); returns 1 when not eligible
+int launch_halo_split(void* stream, const ConvK& k, int Z);
 
 }  // namespace pp

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
   // vector-memory instructions per thread per chunk (an ablation build that drops loads must also stop counting them:
   // a hidden load that lands after its too-lenient wait overwrites a register the compiler has already re-purposed)
   constexpr int NLOADS = ((PP_ABLATE & 4) ? 0 : WPASS) + ((PP_ABLATE & 2) ? 0 : 2 * XPASS);
-  constexpr float LSCALE = 2048.f, LINV = 1.f / 2048.f;
+  constexpr float LINV = 1.f / 2048.f;
 
   unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
 
@@ -183,8 +183,8 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
           const h2 hh = cvt_pkrtz_f16(c0, c1);
           h[e] = hh[0];
           h[e + 1] = hh[1];
-          l[e] = (half_t)((c0 - (float)hh[0]) * LSCALE);
-          l[e + 1] = (half_t)((c1 - (float)hh[1]) * LSCALE);
+          l[e] = (half_t)split_lo(c0, (float)hh[0]);
+          l[e + 1] = (half_t)split_lo(c1, (float)hh[1]);
         } else {  // no arithmetic: the raw bit patterns
           const h2 r0 = __builtin_bit_cast(h2, c0), r1 = __builtin_bit_cast(h2, c1);
           h[e] = r0[0];
@@ -312,6 +312,10 @@ struct SplitFamily {
   static constexpr bool m32_wide96 = false;
 };
 
-int launch_split(void* stream, const ConvK& k, int Z) { return launch_by_cout<SplitFamily<float>>(stream, k, Z); }
+int launch_split(void* stream, const ConvK& k, int Z) {
+  const int rc = launch_halo_split(stream, k, Z);  // stride-1 multi-tap convolutions: pixel tile + halo staged once per chunk
+  if (rc != 1) return rc;
+  return launch_by_cout<SplitFamily<float>>(stream, k, Z);
+}
 
 }  // namespace pp

@@ -154,53 +154,95 @@ struct LookupK {
   int64_t total;  // N*h*w*324
 };
 
-__device__ __forceinline__ float sample_plane(const float* __restrict__ plane, int H, int W, float x, float y) {
-  // grid_sample(bilinear, zeros, align_corners=True) on pixel coordinates after the
-  // normalise -> unnormalise round trip of bilinear_sampler (RAFT/utils/utils.py:69-74)
-  const float xn = 2.f * x / (float)(W - 1) - 1.f;
-  const float yn = 2.f * y / (float)(H - 1) - 1.f;
-  const float ix = ((xn + 1.f) / 2.f) * (float)(W - 1);
-  const float iy = ((yn + 1.f) / 2.f) * (float)(H - 1);
-  const float fx = floorf(ix), fy = floorf(iy);
-  const int x0 = (int)fx, y0 = (int)fy;
-  const float ax = ix - fx, ay = iy - fy;
-  float v = 0.f;
-  const bool xin0 = (x0 >= 0) && (x0 < W), xin1 = (x0 + 1 >= 0) && (x0 + 1 < W);
-  const bool yin0 = (y0 >= 0) && (y0 < H), yin1 = (y0 + 1 >= 0) && (y0 + 1 < H);
-  if (yin0) {
-    const float* r = plane + (int64_t)y0 * W;
-    if (xin0) v += r[x0] * (1.f - ax) * (1.f - ay);
-    if (xin1) v += r[x0 + 1] * ax * (1.f - ay);
-  }
-  if (yin1) {
-    const float* r = plane + (int64_t)(y0 + 1) * W;
-    if (xin0) v += r[x0] * (1.f - ax) * ay;
-    if (xin1) v += r[x0 + 1] * ax * ay;
-  }
-  return v;
-}
+// One wave per (pair, pixel).  The 9x9 bilinear samples of a level touch a 10x10 window of that pixel's correlation
+// plane; the wave first copies a 12x12 window per level (one more row / column each side: the reference's normalise ->
+// unnormalise round trip can move a coordinate across an integer by a few ulps) into LDS with row-contiguous loads
+// -- 576 floats, 9 independent loads per lane, all in flight together -- then every lane evaluates 5-6 of the 324
+// outputs from LDS with the reference's arithmetic and the wave writes 324 contiguous floats.  The previous kernel issued
+// four scattered 4-byte loads per OUTPUT (1296 per pixel instead of 576, no reuse of the window).
+constexpr int kCorrWin = 12;
+constexpr int kCorrLvl = kCorrWin * kCorrWin;
 
 __global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= k.total) return;
-  const int ch = (int)(idx % 324);
-  const int64_t pix = idx / 324;  // n*h*w + y*w + x
-  const int lvl = ch / 81;
-  const int r = ch - lvl * 81;
-  const int i = r / 9, j = r - i * 9;
+  __shared__ float win[4][4 * kCorrLvl];
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const int64_t npix = k.total / 324;
+  const int64_t pix = (int64_t)blockIdx.x * 4 + wave;  // n*h*w + y*w + x
+  const bool active = pix < npix;
+  const int64_t pc = active ? pix : 0;
   const int hw = k.h * k.w;
-  const int p = (int)(pix % hw);
+  const int p = (int)(pc % hw);
   const int py = p / k.w, px = p - py * k.w;
-  const float fx = k.flow[pix * k.flow_ldc + 0];
-  const float fy = k.flow[pix * k.flow_ldc + 1];
-  const float scale = 1.f / (float)(1 << lvl);
-  float cx = ((float)px + fx) * scale + (float)(i - 4);
-  float cy = ((float)py + fy) * scale + (float)(j - 4);
-  if (!(fabsf(cx) < 1.0e8f)) cx = -1.0e8f;  // NaN / Inf flow: out of range, conversions stay defined
-  if (!(fabsf(cy) < 1.0e8f)) cy = -1.0e8f;
-  const int H = k.ph[lvl], W = k.pw[lvl];
-  const float* plane = k.pyr[lvl] + pix * (int64_t)H * W;
-  k.out[pix * k.out_ldc + ch] = sample_plane(plane, H, W, cx, cy);
+  const float fx = k.flow[pc * k.flow_ldc + 0];
+  const float fy = k.flow[pc * k.flow_ldc + 1];
+  float* mywin = win[wave];
+  int ox[4], oy[4];
+#pragma unroll
+  for (int lvl = 0; lvl < 4; ++lvl) {
+    const float scale = 1.f / (float)(1 << lvl);
+    float bx = ((float)px + fx) * scale, by = ((float)py + fy) * scale;
+    if (!(fabsf(bx) < 1.0e6f)) bx = -1.0e6f;  // NaN / Inf / absurd flow: a window far outside the plane (all zeros)
+    if (!(fabsf(by) < 1.0e6f)) by = -1.0e6f;
+    ox[lvl] = (int)floorf(bx) - 5;
+    oy[lvl] = (int)floorf(by) - 5;
+    const int H = k.ph[lvl], W = k.pw[lvl];
+    const float* plane = k.pyr[lvl] + pc * (int64_t)H * W;
+#pragma unroll
+    for (int it = 0; it < (kCorrLvl + 63) / 64; ++it) {
+      const int idx = lane + it * 64;
+      if (idx < kCorrLvl) {
+        const int r = idx / kCorrWin, c = idx - r * kCorrWin;
+        const int y = oy[lvl] + r, x = ox[lvl] + c;
+        const bool in = active && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        mywin[lvl * kCorrLvl + idx] = in ? plane[(int64_t)y * W + x] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+#pragma unroll
+  for (int it = 0; it < (324 + 63) / 64; ++it) {
+    const int ch = lane + it * 64;
+    if (ch >= 324) break;
+    const int lvl = ch / 81;
+    const int r = ch - lvl * 81;
+    const int i = r / 9, j = r - i * 9;
+    const float scale = 1.f / (float)(1 << lvl);
+    float cx = ((float)px + fx) * scale + (float)(i - 4);
+    float cy = ((float)py + fy) * scale + (float)(j - 4);
+    if (!(fabsf(cx) < 1.0e8f)) cx = -1.0e8f;
+    if (!(fabsf(cy) < 1.0e8f)) cy = -1.0e8f;
+    const int H = k.ph[lvl], W = k.pw[lvl];
+    // grid_sample(bilinear, zeros, align_corners=True) after the normalise -> unnormalise round trip of
+    // bilinear_sampler (RAFT/utils/utils.py:69-74), operation by operation
+    const float xn = 2.f * cx / (float)(W - 1) - 1.f;
+    const float yn = 2.f * cy / (float)(H - 1) - 1.f;
+    const float ix = ((xn + 1.f) / 2.f) * (float)(W - 1);
+    const float iy = ((yn + 1.f) / 2.f) * (float)(H - 1);
+    const float flx = floorf(ix), fly = floorf(iy);
+    const float ax = ix - flx, ay = iy - fly;
+    // window-local corner (0 <= l <= 10 for every in-range coordinate; anything else lies outside the plane)
+    int lx = (int)flx, ly = (int)fly;
+    int olx = 0, oly = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (lvl == l) {
+        olx = ox[l];
+        oly = oy[l];
+      }
+    lx -= olx;
+    ly -= oly;
+    float v = 0.f;
+    if ((unsigned)lx < (unsigned)(kCorrWin - 1) && (unsigned)ly < (unsigned)(kCorrWin - 1)) {
+      const float* w0 = mywin + lvl * kCorrLvl + ly * kCorrWin + lx;
+      // out-of-plane corners are staged as 0: the sum below equals the reference's corner-by-corner accumulation
+      v += w0[0] * (1.f - ax) * (1.f - ay);
+      v += w0[1] * ax * (1.f - ay);
+      v += w0[kCorrWin] * (1.f - ax) * ay;
+      v += w0[kCorrWin + 1] * ax * ay;
+    }
+    k.out[pix * k.out_ldc + ch] = v;
+  }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -317,7 +359,7 @@ extern "C" int32_t pp_corr_lookup(void* stream, const pp_corr_lookup_params* p) 
   k.w = (int)p->w;
   k.total = p->N * p->h * p->w * 324;
   if (k.total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_corr_lookup: empty problem");
-  PP_LAUNCH(corr_lookup_kernel, dim3(blocks_for(k.total)), dim3(256), 0, stream, k);
+  PP_LAUNCH(corr_lookup_kernel, dim3((unsigned)((k.total / 324 + 3) / 4)), dim3(256), 0, stream, k);
   return pp_check_launch("pp_corr_lookup");
 }
 

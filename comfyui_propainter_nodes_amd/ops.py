@@ -169,7 +169,7 @@ def split_pack_weight(packed: torch.Tensor) -> torch.Tensor:
     cout, kp = packed.shape
     w = packed.float().reshape(cout, kp // 32, 32)
     h = w.clamp(-65504.0, 65504.0).half()
-    l = ((w - h.float()) * 2048.0).half()
+    l = ((w - h.float()) * 2048.0).clamp(-65504.0, 65504.0).half()  # same saturation as the kernel's split_lo()
     return torch.cat([h, l], dim=2).contiguous().view(torch.float32).reshape(cout, kp)
 
 

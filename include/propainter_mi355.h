@@ -38,7 +38,8 @@ enum pp_dtype {
   PP_U8 = 2,
   PP_I32 = 3,
   /* pp_conv2d only: f32 tensors multiplied on the f16 matrix pipe with two-term operand splits
-   * (v = h + l/2048, three MFMAs per product, fp32 accumulate: fp32-GEMM accuracy for |v| < 32752).
+   * (v = h + l/2048, three MFMAs per product, fp32 accumulate: fp32-GEMM accuracy for |v| < 32752; above that
+   * the low term saturates: absolute error <= 0.016 up to |v| = 65504, values beyond saturate at +-65536, never Inf/NaN).
    * Weights must be in the split packing described at pp_conv2d. */
   PP_F32X2 = 4
 };

@@ -37,6 +37,13 @@ CASES = [
     ("f32x2", 1, 14, 13, [16], 180, 3, 1, 1, 1, 1, "relu"),
     ("f32x2", 1, 12, 10, [16], 6, 1, 1, 0, 1, 1, "tanh"),
     ("f32x2", 1, 12, 10, [16, 8], 24, 3, 1, 1, 1, 2, None),
+    # halo-tile kernel (PP_CONV_HALO=force): several 8x16 output tiles with partial ones in both directions, two images,
+    # segments with a partial 32-channel chunk, every tile family (128 / 96 / 64 channels), 3x3 / 1x5 / 5x1 / 2x3 taps
+    ("f32x2", 2, 19, 37, [40, 8], 130, 3, 1, 1, 1, 1, "relu"),
+    ("f32x2", 1, 17, 33, [36], 192, (1, 5), 1, (0, 2), 1, 1, "sigmoid"),
+    ("f32x2", 1, 21, 18, [64, 4], 64, (5, 1), 1, (2, 0), 1, 1, "tanh"),
+    ("f32x2", 1, 10, 40, [32], 126, (2, 3), 1, (1, 0), 1, 2, None),
+    ("f32x2", 1, 16, 32, [8], 40, 3, 1, 0, 1, 1, "leaky"),
 ]
 
 
@@ -51,9 +58,12 @@ def _ref_input(x, segC, groups):
 
 
 # ("xlforce" = the experimental 8-wave 256-channel tiles: emulator only until they have been measured on the MI355X)
-@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"),
+@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"),
                                      pytest.param("hip", "large", marks=pytest.mark.gpu),
-                                     pytest.param("hip", "small", marks=pytest.mark.gpu)])
+                                     pytest.param("hip", "small", marks=pytest.mark.gpu),
+                                     pytest.param("hip", "xlforce", marks=pytest.mark.gpu),
+                                     pytest.param("hip", "tiny", marks=pytest.mark.gpu),
+                                     pytest.param("hip", "halo", marks=pytest.mark.gpu)])
 def test_conv2d_matches_torch(be, tile):
     """Every case on both tile families (128-pixel tiles / 32-pixel tiles for small problems).  The tile
     choice is read once per process (PP_CONV_TILE), so each family runs in a fresh interpreter."""
@@ -68,6 +78,9 @@ def test_conv2d_matches_torch(be, tile):
         pytest.skip("no GPU visible")
     root = str(Path(__file__).resolve().parent.parent)
     env = dict(os.environ, PP_CONV_TILE=tile, PP_TEST_BACKEND=be, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env["PP_CONV_HALO"] = "0"      # the flat-tile kernels ...
+    if tile == "halo":             # ... or the halo-tile kernel for every eligible PP_F32X2 geometry, whatever its size
+        env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
     r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
@@ -134,7 +147,35 @@ def _run_case(backend, case):
     assert torch.all(buf[..., :4].float().cpu() == 7.0) and torch.all(buf[..., 4 + Cout * groups:].float().cpu() == 7.0)
 
 
-@pytest.mark.parametrize("tile,seed", [("large", 11), ("small", 12), ("xlforce", 13), ("tiny", 14)])
+@pytest.mark.parametrize("halo", ["0", "force"])
+def test_f32x2_operand_range(backend, halo, monkeypatch):
+    """PP_F32X2 at the edge of the f16 range (silent failure for |v| >= 32752).  The low term saturates:
+    inputs up to 65504 stay within fp32-GEMM-like accuracy (absolute operand error <= 0.016), larger inputs saturate at
+    +-65536 -- the result is finite, never Inf/NaN.  Both kernel families (flat 128-pixel tiles / halo tiles)."""
+    monkeypatch.setenv("PP_CONV_HALO", halo)
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C, Cout = 1, 9, 17, 8, 40
+    x = torch.randn(N, H, W, C, generator=g)
+    x[0, 2, 3, 0], x[0, 4, 5, 1], x[0, 6, 7, 2], x[0, 1, 9, 3] = 32751.9, 40007.77, -65503.99, 32783.97
+    w = torch.randn(Cout, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    spec = ops.make_conv_spec(w, b, torch.float32, padding=1, split=True).to(backend)
+    out = torch.empty(N, H, W, Cout, device=backend)
+    ops.conv2d(spec, [x.to(backend)], out)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    err = (out.double().cpu() - ref).abs().max().item()
+    # operand error <= 0.016 per large input, |w| <= ~0.5, at most a few large inputs under one window
+    assert err <= 0.05 + 2e-5 * ref.abs().max().item(), err
+    x2 = x.clone()
+    x2[0, 3, 3, 0], x2[0, 5, 5, 1] = 1.0e6, -3.0e38
+    ops.conv2d(spec, [x2.to(backend)], out)
+    assert torch.isfinite(out).all()
+    sat = x2.clamp(-65536.0, 65536.0)
+    ref2 = F.conv2d(sat.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert (out.double().cpu() - ref2).abs().max().item() <= 0.05 + 2e-5 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("tile,seed", [("large", 11), ("small", 12), ("xlforce", 13), ("tiny", 14), ("halo", 15)])
 def test_conv2d_random_geometries_under_emulation(tile, seed):
     import os
     import subprocess
@@ -142,8 +183,10 @@ def test_conv2d_random_geometries_under_emulation(tile, seed):
     from pathlib import Path
 
     root = str(Path(__file__).resolve().parent.parent)
-    env = dict(os.environ, PP_CONV_TILE=tile, PP_TEST_BACKEND="emu", PP_CONV_RANDOM=str(seed),
+    env = dict(os.environ, PP_CONV_TILE=tile, PP_TEST_BACKEND="emu", PP_CONV_RANDOM=str(seed), PP_CONV_HALO="0",
                PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    if tile == "halo":
+        env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
     r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 

@@ -14,18 +14,19 @@ sys.path.insert(0, str(ROOT / "tools"))
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists(), reason="no hipcc")
-def test_hidden_loads_are_never_touched_in_flight(tmp_path):
+@pytest.mark.parametrize("source,nkernels", [("conv_split.hip", 9), ("conv_halo.hip", 3)])
+def test_hidden_loads_are_never_touched_in_flight(tmp_path, source, nkernels):
     import audit_hidden_loads as A
 
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    src = ROOT / "comfyui_propainter_nodes_amd" / "csrc" / "conv_split.hip"
+    src = ROOT / "comfyui_propainter_nodes_amd" / "csrc" / source
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{ROOT / 'include'}",
            f"-I{src.parent}", "-c", str(src), "-o", str(tmp_path / "conv.o"), "-save-temps=obj"]
     subprocess.run(cmd, check=True, cwd=tmp_path, capture_output=True)
     asm = next(tmp_path.glob("*gfx950*.s"))
     text = asm.read_text()
-    kernels = re.findall(r"^(_ZN2pp\w*conv_split_kernel\w+):", text, flags=re.M)
-    assert len(kernels) == 9  # 7 product tiles + the experimental 8-wave and 16-pixel tiles
+    kernels = re.findall(r"^(_ZN2pp\w*conv_(?:halo_)?split_kernel\w+):", text, flags=re.M)
+    assert len(kernels) == nkernels  # conv_split: 7 flat tiles + the 8-wave and 16-pixel tiles; conv_halo: 128 / 96 / 64 channels
     assert "global_load_lds_dwordx4" in text and ";;#ASMSTART" in text
     assert A.main(str(asm)) == 0
     assert "s_swappc" not in text  # no real calls: helper lambdas are always inlined

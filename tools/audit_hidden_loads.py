@@ -1,6 +1,9 @@
-"""CFG-aware audit of the -save-temps ISA of conv_split.hip: between a hidden (inline-asm) global load and the next
-s_waitcnt vmcnt on every execution path, no instruction may read or write the load's destination registers (hipcc
-does not know they are in flight: a register-allocator copy or reuse there would silently corrupt the tile).
+"""CFG-aware audit of the -save-temps ISA of conv_split.hip / conv_halo.hip: between a hidden (inline-asm) global load
+and the s_waitcnt vmcnt(N) that RETIRES it on every execution path, no instruction may read or write the load's
+destination registers (hipcc does not know they are in flight: a register-allocator copy or reuse there would silently
+corrupt the tile).  Vector-memory loads retire in issue order, so a wait vmcnt(N) retires exactly the loads that have
+at least N younger vector-memory instructions behind them; the audit tracks, per pending register, the minimum number
+of younger instructions over all paths, so a counted wait that leaves the hidden loads in flight does not clear them.
 
 Usage: hipcc ... -c conv_split.hip -save-temps=obj ; python tools/audit_hidden_loads.py <file.s>"""
 import re
@@ -46,16 +49,19 @@ def audit_function(name, lines):
         if fall and i + 1 < len(order):
             s.add(order[i + 1])
         succ[lb] = s
-    entry = {lb: frozenset() for lb in order}
+    VMEM = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "flat_load",
+            "flat_store", "scratch_")
+    CAP = 64
+    entry = {lb: {} for lb in order}   # register -> minimum number of younger vector-memory instructions
     bad = []
     changed = True
     rounds = 0
-    while changed and rounds < 50:
+    while changed and rounds < 200:
         changed = False
         rounds += 1
         bad = []
         for lb in order:
-            pending = set(entry[lb])
+            pending = dict(entry[lb])
             body = blocks[lb]
             for i, l in enumerate(body):
                 if not l or l[0] in ".;":
@@ -63,26 +69,37 @@ def audit_function(name, lines):
                 if l.startswith("global_load_dwordx4") and i > 0 and body[i - 1].startswith(";;#ASMSTART"):
                     m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", l)
                     addr = regs_of(l.split(",", 1)[1])
-                    if addr & pending:
+                    if addr & set(pending):
                         bad.append((lb, l))
-                    pending.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                    for r in pending:
+                        pending[r] = min(CAP, pending[r] + 1)
+                    for r in range(int(m.group(1)), int(m.group(2)) + 1):
+                        pending[r] = 0
                     continue
                 if l.startswith("s_waitcnt") and "vmcnt" in l:
-                    pending.clear()
+                    n = int(re.search(r"vmcnt\((\d+)\)", l).group(1))
+                    pending = {r: k for r, k in pending.items() if k < n}
                     continue
-                if regs_of(l) & pending:
+                if regs_of(l) & set(pending):
                     bad.append((lb, l))
+                if l.startswith(VMEM):
+                    for r in pending:
+                        pending[r] = min(CAP, pending[r] + 1)
             for t in succ[lb]:
-                if t in entry and not pending <= entry[t]:
-                    entry[t] = frozenset(entry[t] | pending)
-                    changed = True
+                if t not in entry:
+                    continue
+                tgt = entry[t]
+                for r, k in pending.items():
+                    if r not in tgt or k < tgt[r]:
+                        tgt[r] = k
+                        changed = True
     return bad
 
 
 def main(path):
     s = open(path).read()
     total = 0
-    for m in re.finditer(r"^(_ZN2pp\w*conv_split_kernel\w+):", s, flags=re.M):
+    for m in re.finditer(r"^(_ZN2pp\w*conv_(?:halo_)?split_kernel\w+):", s, flags=re.M):
         a = m.end()
         b = s.index(".Lfunc_end", a)
         bad = audit_function(m.group(1), s[a:b].split("\n"))
