@@ -253,7 +253,10 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
 
 // f32 convolution on the f16 matrix pipe (PP_F32X2): conv_split.hip
 int launch_split(void* stream, const ConvK& k, int Z);
+// f16 convolutions with few output pixels and a long reduction (conv_ksplit.hip); returns 1 when not eligible
+int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // ... and its halo-tile form for stride-1 multi-tap convolutions (conv_halo.hip); returns 1 when not eligible
 int launch_halo_split(void* stream, const ConvK& k, int Z);
+int launch_halo_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 
 }  // namespace pp

@@ -516,6 +516,10 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   if (p->pre_add && p->Z != 1) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: pre_add with Z > 1");
   const int Z = (int)p->Z;
   if (p->dtype == PP_F16) {
+    const int rc = launch_ksplit_f16(stream, k, Z, p->out_dtype == PP_F16);  // small M, long K: in-work-group split K
+    if (rc != 1) return rc;
+    const int rh = launch_halo_f16(stream, k, Z, p->out_dtype == PP_F16);  // stride-1 multi-tap: pixel tile + halo staged once per chunk
+    if (rh != 1) return rh;
     if (p->out_dtype == PP_F16) return launch_by_cout<IgemmFamily<half_t, half_t>>(stream, k, Z);
     return launch_by_cout<IgemmFamily<half_t, float>>(stream, k, Z);
   }

@@ -5,40 +5,63 @@
 #include "pp_device.h"
 #include "pp_host.h"
 
+#include <type_traits>
+
 namespace pp {
 
 // ----------------------------------------------------------------------------------------
 // im2col
 // ----------------------------------------------------------------------------------------
+// One thread writes 16 bytes (4 f32 / 8 f16 consecutive k of one output pixel): the pixel decode (three integer
+// divisions) is shared by the group and the patch matrix leaves in whole 16-byte stores.
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) im2col_kernel(const TI* __restrict__ in, int in_ldc, int N, int H, int W, int C,
                                                       int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
                                                       int pad_mode, TO* __restrict__ out, int Kpad, int64_t total) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  constexpr int VEC = 16 / (int)sizeof(TO);
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over M * Kpad / VEC
   if (idx >= total) return;
-  const int k = (int)(idx % Kpad);
-  const int64_t m = idx / Kpad;
-  float v = 0.f;
-  if (k < kh * kw * C) {
-    const int c = k % C;
-    const int tap = k / C;
-    const int ky = tap / kw, kx = tap % kw;
-    const int wo = (int)(m % Wo);
-    const int64_t t = m / Wo;
-    const int ho = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-    int y = ho * sh - ph + ky;
-    int x = wo * sw - pw + kx;
-    bool ok = true;
-    if (pad_mode == PP_PAD_REPLICATE) {
-      y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-      x = x < 0 ? 0 : (x >= W ? W - 1 : x);
-    } else {
-      ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+  const int groups = Kpad / VEC;
+  const int k0 = (int)(idx % groups) * VEC;
+  const int64_t m = idx / groups;
+  const int wo = (int)(m % Wo);
+  const int64_t t = m / Wo;
+  const int ho = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  const int y0 = ho * sh - ph, x0 = wo * sw - pw;
+  const TI* img = in + (int64_t)n * H * W * in_ldc;
+  const int kvalid = kh * kw * C;
+  int c = k0 % C, tap = k0 / C;
+  int ky = tap / kw, kx = tap - ky * kw;
+  TO vals[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float v = 0.f;
+    if (k0 + e < kvalid) {
+      int y = y0 + ky, x = x0 + kx;
+      bool ok = true;
+      if (pad_mode == PP_PAD_REPLICATE) {
+        y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+        x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+      } else {
+        ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+      }
+      if (ok) v = to_f32(img[((int64_t)y * W + x) * in_ldc + c]);
     }
-    if (ok) v = to_f32(in[(((int64_t)n * H + y) * W + x) * in_ldc + c]);
+    vals[e] = from_f32<TO>(v);
+    if (++c == C) {
+      c = 0;
+      if (++kx == kw) {
+        kx = 0;
+        ++ky;
+      }
+    }
   }
-  out[idx] = from_f32<TO>(v);
+  typedef typename std::conditional<sizeof(TO) == 4, f4, h8>::type vec_t;
+  vec_t o;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) o[e] = vals[e];
+  *reinterpret_cast<vec_t*>(out + m * Kpad + k0) = o;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -293,7 +316,8 @@ extern "C" int32_t pp_im2col(void* stream, const pp_im2col_params* p) {
   using namespace pp;
   if (!p || !p->in || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_im2col: null argument");
   if (p->Kpad < (int64_t)p->kh * p->kw * p->C) return pp_fail(PP_ERR_BAD_ARG, "pp_im2col: Kpad too small");
-  const int64_t total = p->N * p->Ho * p->Wo * p->Kpad;
+  if (p->Kpad % 8) return pp_fail(PP_ERR_BAD_ARG, "pp_im2col: Kpad must be a multiple of 8");
+  const int64_t total = p->N * p->Ho * p->Wo * (p->Kpad / (p->out_dtype == PP_F16 ? 8 : 4));  // 16-byte groups
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_im2col: empty problem");
 #define PP_IM2COL(TI, TO)                                                                                         \
   PP_LAUNCH((im2col_kernel<TI, TO>), dim3(blocks_for(total)), dim3(256), 0, stream, (const TI*)p->in,            \

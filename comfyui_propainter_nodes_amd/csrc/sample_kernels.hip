@@ -176,9 +176,10 @@ __global__ void __launch_bounds__(256) upsample2x_h8_kernel(const half_t* __rest
 // ----------------------------------------------------------------------------------------
 // flow-completion input / output passes
 // ----------------------------------------------------------------------------------------
+template <typename OT>
 __global__ void __launch_bounds__(256) rfc_prep_kernel(const float* __restrict__ flows,
                                                        const unsigned char* __restrict__ masks,
-                                                       half_t* __restrict__ out, int T, int64_t HW, int64_t total) {
+                                                       OT* __restrict__ out, int T, int64_t HW, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [2][T][HW]
   if (idx >= total) return;
   const int64_t p = idx % HW;
@@ -188,12 +189,17 @@ __global__ void __launch_bounds__(256) rfc_prep_kernel(const float* __restrict__
   const float m = masks[(int64_t)(t + d) * HW + p] ? 1.f : 0.f;
   const float* f = flows + idx * 2;
   const int to = d ? (T - 1 - t) : t;
-  half_t* o = out + (((int64_t)to * 2 + d) * HW + p) * 4;
-  h4 v = {(half_t)(f[0] * (1.f - m)), (half_t)(f[1] * (1.f - m)), (half_t)m, (half_t)0.f};
-  *reinterpret_cast<h4*>(o) = v;
+  OT* o = out + (((int64_t)to * 2 + d) * HW + p) * 4;
+  if constexpr (sizeof(OT) == 2) {
+    h4 v = {(half_t)(f[0] * (1.f - m)), (half_t)(f[1] * (1.f - m)), (half_t)m, (half_t)0.f};
+    *reinterpret_cast<h4*>(o) = v;
+  } else {
+    *reinterpret_cast<f4*>(o) = f4{f[0] * (1.f - m), f[1] * (1.f - m), m, 0.f};
+  }
 }
 
-__global__ void __launch_bounds__(256) flow_combine_kernel(const half_t* __restrict__ pred, int pred_ldc,
+template <typename PT>
+__global__ void __launch_bounds__(256) flow_combine_kernel(const PT* __restrict__ pred, int pred_ldc,
                                                            const float* __restrict__ flows,
                                                            const unsigned char* __restrict__ masks,
                                                            float* __restrict__ out, int T, int64_t HW, int64_t total) {
@@ -205,7 +211,7 @@ __global__ void __launch_bounds__(256) flow_combine_kernel(const half_t* __restr
   const int d = (int)(r / T);
   const float m = masks[(int64_t)(t + d) * HW + p] ? 1.f : 0.f;
   const int tp = d ? (T - 1 - t) : t;
-  const half_t* pr = pred + (((int64_t)tp * 2 + d) * HW + p) * pred_ldc;
+  const PT* pr = pred + (((int64_t)tp * 2 + d) * HW + p) * pred_ldc;
   const float* f = flows + idx * 2;
   out[idx * 2 + 0] = (float)pr[0] * m + f[0] * (1.f - m);
   out[idx * 2 + 1] = (float)pr[1] * m + f[1] * (1.f - m);
@@ -266,8 +272,15 @@ extern "C" int32_t pp_rfc_prep(void* stream, const pp_rfc_prep_params* p) {
   const int64_t HW = p->H * p->W;
   const int64_t total = 2 * p->T * HW;
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_rfc_prep: empty problem");
-  PP_LAUNCH(rfc_prep_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const float*)p->flows,
-            (const unsigned char*)p->masks, (half_t*)p->out, (int)p->T, HW, total);
+  if (p->out_dtype == PP_F16) {
+    PP_LAUNCH((rfc_prep_kernel<half_t>), dim3(nblk(total)), dim3(256), 0, stream, (const float*)p->flows,
+              (const unsigned char*)p->masks, (half_t*)p->out, (int)p->T, HW, total);
+  } else if (p->out_dtype == PP_F32) {
+    PP_LAUNCH((rfc_prep_kernel<float>), dim3(nblk(total)), dim3(256), 0, stream, (const float*)p->flows,
+              (const unsigned char*)p->masks, (float*)p->out, (int)p->T, HW, total);
+  } else {
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_rfc_prep: out_dtype");
+  }
   return pp_check_launch("pp_rfc_prep");
 }
 
@@ -277,7 +290,14 @@ extern "C" int32_t pp_flow_combine(void* stream, const pp_flow_combine_params* p
   const int64_t HW = p->H * p->W;
   const int64_t total = 2 * p->T * HW;
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_flow_combine: empty problem");
-  PP_LAUNCH(flow_combine_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const half_t*)p->pred, (int)p->pred_ldc,
-            (const float*)p->flows, (const unsigned char*)p->masks, (float*)p->out, (int)p->T, HW, total);
+  if (p->pred_dtype == PP_F16) {
+    PP_LAUNCH((flow_combine_kernel<half_t>), dim3(nblk(total)), dim3(256), 0, stream, (const half_t*)p->pred,
+              (int)p->pred_ldc, (const float*)p->flows, (const unsigned char*)p->masks, (float*)p->out, (int)p->T, HW, total);
+  } else if (p->pred_dtype == PP_F32) {
+    PP_LAUNCH((flow_combine_kernel<float>), dim3(nblk(total)), dim3(256), 0, stream, (const float*)p->pred,
+              (int)p->pred_ldc, (const float*)p->flows, (const unsigned char*)p->masks, (float*)p->out, (int)p->T, HW, total);
+  } else {
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_flow_combine: pred_dtype");
+  }
   return pp_check_launch("pp_flow_combine");
 }

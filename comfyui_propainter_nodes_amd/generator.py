@@ -16,7 +16,7 @@ import math
 
 import torch
 
-from . import ops
+from . import graphs, ops
 
 F16 = torch.float16
 WIN = (5, 9)
@@ -43,6 +43,7 @@ class ClipState:
 class InpaintGeneratorMI355:
     def __init__(self, sd: dict, device):
         self.device = torch.device(device)
+        self._graphs = graphs.GraphCache()
         p = {k: v.float() for k, v in sd.items() if v.is_floating_point()}
         dev = device
 
@@ -184,10 +185,16 @@ class InpaintGeneratorMI355:
         return result  # type: ignore[return-value]
 
     def _feature_propagation_batch(self, st: ClipState, g0s: list[int], lt: int) -> torch.Tensor:
-        """nw windows starting at clip frames g0s, each with lt local frames -> f16 [lt, nw, h, w, 128]."""
-        dev = st.enc.device
+        """nw windows starting at clip frames g0s, each with lt local frames -> f16 [lt, nw, h, w, 128].  The sweep is
+        2 x lt steps of ~10 small dependent launches: captured once per (window set, clip shape) into a hipGraph and
+        replayed on static copies of the per-clip tensors (graphs.py)."""
+        return self._graphs.run(("featprop", tuple(g0s), lt), lambda *t: self._featprop_eager(g0s, lt, *t),
+                                st.enc, st.maskpair, st.flow_f, st.flow_b, st.aux_b, st.aux_f)
+
+    def _featprop_eager(self, g0s: list[int], lt: int, enc, maskpair, flow_f, flow_b, aux_b, aux_f) -> torch.Tensor:
+        dev = enc.device
         nw = len(g0s)
-        _, h, w, _ = st.enc.shape
+        _, h, w, _ = enc.shape
 
         def gather(t: torch.Tensor, idx: int) -> torch.Tensor:
             return t.index_select(0, ops.device_ints([g + idx for g in g0s], dev))  # [nw, ...] rows (plain copy)
@@ -195,8 +202,8 @@ class InpaintGeneratorMI355:
         def buf(c, dt=F16):
             return torch.empty(nw, h, w, c, device=dev, dtype=dt)
 
-        x = torch.stack([gather(st.enc, i) for i in range(lt)], 0)            # [lt,nw,h,w,128]
-        mp = torch.stack([gather(st.maskpair, i) for i in range(lt)], 0)      # [lt,nw,h,w,8]
+        x = torch.stack([gather(enc, i) for i in range(lt)], 0)            # [lt,nw,h,w,128]
+        mp = torch.stack([gather(maskpair, i) for i in range(lt)], 0)      # [lt,nw,h,w,8]
         t128, u128, warped, aligned = buf(128), buf(128), buf(128), buf(128)
         om = buf(432, torch.float32)
         cols = buf(9 * 128)
@@ -213,9 +220,9 @@ class InpaintGeneratorMI355:
                     prop = cur
                 else:
                     if name == "backward_1":   # frame g uses flows_forward[g] / aux_b[g]
-                        flow, aux = gather(st.flow_f, idx), gather(st.aux_b, idx)
+                        flow, aux = gather(flow_f, idx), gather(aux_b, idx)
                     else:                      # frame g uses flows_backward[g-1] / aux_f[g-1]
-                        flow, aux = gather(st.flow_b, idx - 1), gather(st.aux_f, idx - 1)
+                        flow, aux = gather(flow_b, idx - 1), gather(aux_f, idx - 1)
                     ops.flow_warp(prop, flow, warped)
                     ops.conv2d(S["off0"], [cur, warped, aux], t128, act="leaky", act_param=0.1)
                     ops.conv2d(S["off2"], [t128], u128, act="leaky", act_param=0.1)

@@ -488,7 +488,7 @@ def upsample2x(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 
 def rfc_prep(flows: torch.Tensor, masks_u8: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """flows fp32 [2,T,H,W,2], masks u8 [T+1,H,W] -> out f16 [T,2,H,W,4] (direction 1 time-flipped)."""
+    """flows fp32 [2,T,H,W,2], masks u8 [T+1,H,W] -> out f16 / f32 [T,2,H,W,4] (direction 1 time-flipped)."""
     check_device(flows, masks_u8, out)
     _, t, h, w, _ = flows.shape
     if not (flows.is_contiguous() and masks_u8.is_contiguous() and out.is_contiguous()):
@@ -497,18 +497,19 @@ def rfc_prep(flows: torch.Tensor, masks_u8: torch.Tensor, out: torch.Tensor) -> 
         raise ValueError("rfc_prep: bad shapes")
     P = _lib.STRUCTS["pp_rfc_prep_params"]()
     P.flows, P.masks, P.out, P.T, P.H, P.W = flows.data_ptr(), masks_u8.data_ptr(), out.data_ptr(), t, h, w
+    P.out_dtype = dtype_code(out.dtype)
     _call("pp_rfc_prep", out, P)
     return out
 
 
 def flow_combine(pred: torch.Tensor, flows: torch.Tensor, masks_u8: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """pred f16 [T,2,H,W,>=2] (direction 1 time-flipped) + gt flows fp32 [2,T,H,W,2] -> out fp32 [2,T,H,W,2]."""
+    """pred f16 / f32 [T,2,H,W,>=2] (direction 1 time-flipped) + gt flows fp32 [2,T,H,W,2] -> out fp32 [2,T,H,W,2]."""
     check_device(pred, flows, masks_u8, out)
     _, t, h, w, _ = flows.shape
-    if pred.dtype != torch.float16 or tuple(pred.shape[:4]) != (t, 2, h, w):
+    if pred.dtype not in (torch.float16, torch.float32) or tuple(pred.shape[:4]) != (t, 2, h, w):
         raise ValueError("flow_combine: bad pred")
     P = _lib.STRUCTS["pp_flow_combine_params"]()
-    P.pred, P.pred_ldc = pred.data_ptr(), pred.stride(3)
+    P.pred, P.pred_ldc, P.pred_dtype = pred.data_ptr(), pred.stride(3), dtype_code(pred.dtype)
     P.flows, P.masks, P.out, P.T, P.H, P.W = flows.data_ptr(), masks_u8.data_ptr(), out.data_ptr(), t, h, w
     _call("pp_flow_combine", out, P)
     return out

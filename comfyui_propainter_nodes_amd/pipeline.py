@@ -100,9 +100,9 @@ def initialize_models(device: torch.device, use_half: str = "enable", seed: int 
     garbage; seeded synthetic weights are an explicit opt-in for benchmarks and tests
     (PP_ALLOW_SYNTHETIC_WEIGHTS=1)."""
     if use_half == "disable":
-        _warn_once("fp16='disable': RAFT runs on fp32 tensors as in the reference; flow completion and the generator keep "
-                   "f16 storage with fp32 accumulation / statistics / coordinates in this build (>= 60 dB against the "
-                   "fp32 reference on the parity fixtures) - there is no fp32-storage mode for those two networks yet")
+        _warn_once("fp16='disable': RAFT and flow completion run on fp32 tensors as in the reference; the generator keeps "
+                   "f16 storage with fp32 accumulation / statistics / coordinates in this build (>= 58 dB against the "
+                   "fp32 reference on the parity fixtures) - there is no fp32-storage mode for that network yet")
     if weights.weights_available():
         ident = tuple((f, (weights.WEIGHT_DIR / f).stat().st_size, (weights.WEIGHT_DIR / f).stat().st_mtime_ns)
                       for f in weights.FILES.values())
@@ -114,19 +114,20 @@ def initialize_models(device: torch.device, use_half: str = "enable", seed: int 
         raise FileNotFoundError(
             f"ProPainter checkpoints not found in {weights.WEIGHT_DIR}: place {', '.join(weights.FILES.values())} "
             f"(release {weights.RELEASE_URL}) there. Set PP_ALLOW_SYNTHETIC_WEIGHTS=1 only for benchmarks / tests.")
-    key = (str(device), ops.f32_split_enabled(), ident)
+    key = (str(device), ops.f32_split_enabled(), use_half, ident)
     if key not in _MODEL_CACHE:
         if len(_MODEL_CACHE) >= 2:  # a stale entry pins three networks in HBM: keep at most the previous one
             _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))
         sds, prov = weights.get_state_dicts(seed)
-        _MODEL_CACHE[key] = Models(RaftFlow(sds["raft"], device), FlowCompleter(sds["rfc"], device),
-                                   InpaintGeneratorMI355(sds["gen"], device), prov)
+        _MODEL_CACHE[key] = models_from_state_dicts(sds, device, use_half, prov)
     return _MODEL_CACHE[key]
 
 
-def models_from_state_dicts(sds: dict, device) -> Models:
-    return Models(RaftFlow(sds["raft"], device), FlowCompleter(sds["rfc"], device), InpaintGeneratorMI355(sds["gen"], device),
-                  "explicit")
+def models_from_state_dicts(sds: dict, device, fp16: str = "enable", provenance: str = "explicit") -> Models:
+    """RAFT is fp32 in both modes (utils/model_utils.py:55-56); fp16 "disable" keeps flow completion in fp32 too."""
+    rfc_dtype = torch.float16 if fp16 == "enable" else torch.float32
+    return Models(RaftFlow(sds["raft"], device), FlowCompleter(sds["rfc"], device, rfc_dtype),
+                  InpaintGeneratorMI355(sds["gen"], device), provenance)
 
 
 def compute_flow(raft_model: RaftFlow, frames: torch.Tensor, config: ProPainterConfig) -> torch.Tensor:

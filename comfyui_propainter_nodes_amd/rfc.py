@@ -16,30 +16,36 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import graphs, ops
 
 F16 = torch.float16
 
 
 class FlowCompleter:
-    def __init__(self, sd: dict, device):
+    def __init__(self, sd: dict, device, dtype: torch.dtype = F16):
+        """`dtype` = storage type of the activations: f16 (the node's fp16 "enable": the reference runs this net
+        `.half()`) or f32 (fp16 "disable": fp32 like the reference; the convolutions then multiply on the f16 matrix pipe
+        with the two-term operand split of PP_F32X2, or on the f32 MFMA instructions under PP_F32_GEMM=exact)."""
         self.device = torch.device(device)
+        self.dt = dtype
+        self.split = dtype == torch.float32 and ops.f32_split_enabled()
+        self._graphs = graphs.GraphCache()
         p = {k: v.float() for k, v in sd.items() if not k.startswith("edgeDetector")}
 
         def c2(name, **kw):  # Conv3d (1,k,k) or Conv2d
             w = p[name + ".weight"]
             if w.dim() == 5:
                 w = w[:, :, 0]
-            return ops.make_conv_spec(w, p[name + ".bias"], F16, **kw).to(device)
+            return ops.make_conv_spec(w, p[name + ".bias"], self.dt, split=self.split, **kw).to(device)
 
         def ct(name):  # Conv3d (3,1,1), dilation 2, padding 2 -> kernel 3x1 over [T] x [pixels]
             w = p[name + ".weight"][:, :, :, 0, 0].unsqueeze(-1)  # [Co,Ci,3,1]
-            return ops.make_conv_spec(w, p[name + ".bias"], F16, padding=(2, 0), dilation=(2, 1)).to(device)
+            return ops.make_conv_spec(w, p[name + ".bias"], self.dt, padding=(2, 0), dilation=(2, 1), split=self.split).to(device)
 
         wd = p["downsample.0.weight"][:, :, 0]  # [32,3,5,5] -> im2col GEMM (replicate padding)
         self.down_kpad = ops.pad32(75)
-        self.down = ops.make_conv_spec(wd.permute(0, 2, 3, 1).reshape(32, 75, 1, 1), p["downsample.0.bias"], F16,
-                                       seg_channels=[self.down_kpad], seg_valid=[75]).to(device)
+        self.down = ops.make_conv_spec(wd.permute(0, 2, 3, 1).reshape(32, 75, 1, 1), p["downsample.0.bias"], self.dt,
+                                       seg_channels=[self.down_kpad], seg_valid=[75], split=self.split).to(device)
         self.enc = [
             (c2("encoder1.0.conv1.0", padding=1), ct("encoder1.0.conv2.0")),
             (c2("encoder1.2.conv1.0", stride=2, padding=1), ct("encoder1.2.conv2.0")),
@@ -57,7 +63,7 @@ class FlowCompleter:
                 "off2": c2(da + "conv_offset.2", padding=1),
                 "off4": c2(da + "conv_offset.4", padding=1),
                 "off6": c2(da + "conv_offset.6", padding=1),
-                "dcn": ops.make_conv_spec(wm.permute(0, 2, 3, 1).reshape(128, 9 * 256, 1, 1), p[da + "bias"], F16).to(device),
+                "dcn": ops.make_conv_spec(wm.permute(0, 2, 3, 1).reshape(128, 9 * 256, 1, 1), p[da + "bias"], self.dt, split=self.split).to(device),
                 "bb0": c2(f"{fp}backbone.{name}.0", padding=1, seg_channels=[128] * nseg),
                 "bb2": c2(f"{fp}backbone.{name}.2", padding=1),
             }
@@ -76,18 +82,18 @@ class FlowCompleter:
         T, B, H, W, _ = x.shape
         n = T * B
         h2, w2 = (H + 4 - 5) // 2 + 1, (W + 4 - 5) // 2 + 1
-        cols = torch.empty(n, h2, w2, self.down_kpad, device=dev, dtype=F16)
+        cols = torch.empty(n, h2, w2, self.down_kpad, device=dev, dtype=self.dt)
         ops.im2col(x.view(n, H, W, 4)[..., 0:3], cols, 5, 5, stride=2, padding=2, pad_mode="replicate")
-        cur = torch.empty(n, h2, w2, 32, device=dev, dtype=F16)
+        cur = torch.empty(n, h2, w2, 32, device=dev, dtype=self.dt)
         ops.conv2d(self.down, [cols], cur, act="leaky", act_param=0.2)
         del cols
         e1 = None
         for li, (sp, tp) in enumerate(self.enc):
             _, h, w, _ = cur.shape
             ho, wo = sp.out_hw(h, w)
-            a = torch.empty(n, ho, wo, sp.cout, device=dev, dtype=F16)
+            a = torch.empty(n, ho, wo, sp.cout, device=dev, dtype=self.dt)
             ops.conv2d(sp, [cur], a, act="leaky", act_param=0.2)
-            b = torch.empty(n, ho, wo, sp.cout, device=dev, dtype=F16)
+            b = torch.empty(n, ho, wo, sp.cout, device=dev, dtype=self.dt)
             # temporal conv: rows = T, columns = B*ho*wo pixels
             ops.conv2d(tp, [a.view(1, T, B * ho * wo, sp.cout)], b.view(1, T, B * ho * wo, sp.cout), act="leaky",
                        act_param=0.2)
@@ -101,21 +107,28 @@ class FlowCompleter:
         _, h8, w8, _ = cur.shape
         return e1, cur.view(T, B, h8, w8, 128)
 
-    def _propagate(self, mid: torch.Tensor) -> torch.Tensor:
+    def _propagate(self, mid: torch.Tensor, capture: bool = True) -> torch.Tensor:
+        """The two sweeps are ~16 small dependent launches per frame: captured once per clip shape into a hipGraph and
+        replayed (graphs.py); the result lives in the graph's static buffer until the next call with this shape."""
+        if not capture:
+            return self._propagate_eager(mid)
+        return self._graphs.run(("rfc_propagate",), self._propagate_eager, mid)
+
+    def _propagate_eager(self, mid: torch.Tensor) -> torch.Tensor:
         """BidirectionalPropagation.forward (:77-143) on mid [T,2,h,w,128] -> [T,2,h,w,128]."""
         dev = mid.device
         T, B, h, w, C = mid.shape
         outs = {}
-        zeros = torch.zeros(B, h, w, C, device=dev, dtype=F16)
-        t128 = torch.empty(B, h, w, 128, device=dev, dtype=F16)
-        u128 = torch.empty(B, h, w, 128, device=dev, dtype=F16)
+        zeros = torch.zeros(B, h, w, C, device=dev, dtype=self.dt)
+        t128 = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
+        u128 = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
         om = torch.empty(B, h, w, 432, device=dev, dtype=torch.float32)
-        cols = torch.empty(B, h, w, 9 * 256, device=dev, dtype=F16)
-        aligned = torch.empty(B, h, w, 128, device=dev, dtype=F16)
+        cols = torch.empty(B, h, w, 9 * 256, device=dev, dtype=self.dt)
+        aligned = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
         for name in ("backward_", "forward_"):
             S = self.prop[name]
             order = list(range(T - 1, -1, -1)) if name == "backward_" else list(range(T))
-            out = torch.empty(T, B, h, w, C, device=dev, dtype=F16)
+            out = torch.empty(T, B, h, w, C, device=dev, dtype=self.dt)
             prop = zeros
             for i, idx in enumerate(order):
                 cur = mid[idx]
@@ -134,7 +147,7 @@ class FlowCompleter:
                 ops.conv2d(S["bb2"], [t128], out[idx], epi="add", aux1=prop)
                 prop = out[idx]
             outs[name] = out
-        fused = torch.empty(T * B, h, w, C, device=dev, dtype=F16)
+        fused = torch.empty(T * B, h, w, C, device=dev, dtype=self.dt)
         ops.conv2d(self.fusion, [outs["backward_"].view(T * B, h, w, C), outs["forward_"].view(T * B, h, w, C)], fused,
                    epi="add", aux1=mid.view(T * B, h, w, C))
         return fused
@@ -144,7 +157,7 @@ class FlowCompleter:
         n, h, w, _ = prop.shape
 
         def new(hh, ww, c):
-            return torch.empty(n, hh, ww, c, device=dev, dtype=F16)
+            return torch.empty(n, hh, ww, c, device=dev, dtype=self.dt)
 
         a = ops.conv2d(self.dec2_0, [prop], new(h, w, 128), act="leaky", act_param=0.2)
         up = ops.upsample2x(a, new(2 * h, 2 * w, 128))
@@ -160,10 +173,10 @@ class FlowCompleter:
         """flows fp32 [2,T,H,W,2] (forward, backward), masks u8 [T+1,H,W] (flow masks of the T+1 frames)
         -> completed + combined flows fp32 [2,T,H,W,2]."""
         _, T, H, W, _ = flows.shape
-        x = torch.empty(T, 2, H, W, 4, device=flows.device, dtype=F16)
+        x = torch.empty(T, 2, H, W, 4, device=flows.device, dtype=self.dt)
         ops.rfc_prep(flows, masks_u8, x)
         e1, mid = self._encode(x)
-        prop = self._propagate(mid)
+        prop = self._propagate(mid, capture=trace is None)
         pred = self._decode(prop, e1).view(T, 2, H, W, 2)
         if trace is not None:
             trace.update(mid=mid, prop=prop, pred=pred)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 1
+#define PP_ABI_VERSION 2
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -261,15 +261,16 @@ int32_t pp_upsample2x(void* stream, const pp_upsample2x_params* p);
  * pp_rfc_prep -- input of RecurrentFlowCompleteNet (recurrent_flow_completion.py:366-377,
  * 322-325): out[t'][d][y][x] = (flow*(1-m), m, 0) as 4 f16 channels, for direction d = 0
  * (forward flows, masks[:-1]) and d = 1 (backward flows, masks[1:], TIME-FLIPPED: t' = T-1-t).
- * flows: fp32 [2][T][H][W][2]; masks: u8 [T+1][H][W]; out: f16 [T][2][H][W][4].
+ * flows: fp32 [2][T][H][W][2]; masks: u8 [T+1][H][W]; out: f16 / f32 [T][2][H][W][4].
  * pp_flow_combine -- combine_flow (:389-400) incl. the flip back:
- * out[d][t] = pred*m + gt*(1-m), pred f16 [T][2][H][W][2] (time-flipped for d = 1).
+ * out[d][t] = pred*m + gt*(1-m), pred f16 / f32 [T][2][H][W][2] (time-flipped for d = 1).
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const void* flows;
   const void* masks;
   void* out;
   int64_t T, H, W;
+  int32_t out_dtype; /* PP_F16 (fp16 "enable") or PP_F32 (fp16 "disable"): storage type of the network's activations */
 } pp_rfc_prep_params;
 int32_t pp_rfc_prep(void* stream, const pp_rfc_prep_params* p);
 
@@ -280,6 +281,7 @@ typedef struct {
   const void* masks;
   void* out; /* fp32 [2][T][H][W][2] */
   int64_t T, H, W;
+  int32_t pred_dtype; /* PP_F16 or PP_F32 */
 } pp_flow_combine_params;
 int32_t pp_flow_combine(void* stream, const pp_flow_combine_params* p);
 

@@ -44,6 +44,17 @@ CASES = [
     ("f32x2", 1, 21, 18, [64, 4], 64, (5, 1), 1, (2, 0), 1, 1, "tanh"),
     ("f32x2", 1, 10, 40, [32], 126, (2, 3), 1, (1, 0), 1, 2, None),
     ("f32x2", 1, 16, 32, [8], 40, 3, 1, 0, 1, 1, "leaky"),
+    # f16 halo-tile kernel: several tiles, segments with a partial chunk, dilation 2 (the 5-pass pixel stage), 96 / 64 tiles
+    (torch.float16, 2, 19, 37, [40, 24], 130, 3, 1, 1, 1, 1, "relu"),
+    (torch.float16, 1, 17, 33, [32], 192, 3, 1, 2, 2, 1, "leaky"),
+    (torch.float16, 1, 12, 20, [64, 8], 64, (3, 1), 1, (2, 0), (2, 1), 1, None),
+    # in-work-group split-K kernel (PP_CONV_KSPLIT=force): reductions of 9 / 27 / 45 / 10 chunks over 4 groups, segments,
+    # a last group with fewer (or no) chunks, partial 32-pixel and 128-channel tiles
+    (torch.float16, 1, 7, 9, [32], 128, 3, 1, 1, 1, 1, "leaky"),
+    (torch.float16, 2, 6, 5, [40, 24, 16], 130, 3, 1, 1, 1, 1, None),
+    (torch.float16, 1, 9, 8, [64, 96], 96, 3, 1, 1, 1, 1, "relu"),
+    (torch.float16, 1, 5, 13, [320], 140, 1, 1, 0, 1, 1, "tanh"),
+    (torch.float16, 1, 8, 8, [16], 72, (1, 5), 1, (0, 2), 1, 1, None),
 ]
 
 
@@ -58,12 +69,13 @@ def _ref_input(x, segC, groups):
 
 
 # ("xlforce" = the experimental 8-wave 256-channel tiles: emulator only until they have been measured on the MI355X)
-@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"),
+@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"), ("emu", "ksplit"),
                                      pytest.param("hip", "large", marks=pytest.mark.gpu),
                                      pytest.param("hip", "small", marks=pytest.mark.gpu),
                                      pytest.param("hip", "xlforce", marks=pytest.mark.gpu),
                                      pytest.param("hip", "tiny", marks=pytest.mark.gpu),
-                                     pytest.param("hip", "halo", marks=pytest.mark.gpu)])
+                                     pytest.param("hip", "halo", marks=pytest.mark.gpu),
+                                     pytest.param("hip", "ksplit", marks=pytest.mark.gpu)])
 def test_conv2d_matches_torch(be, tile):
     """Every case on both tile families (128-pixel tiles / 32-pixel tiles for small problems).  The tile
     choice is read once per process (PP_CONV_TILE), so each family runs in a fresh interpreter."""
@@ -79,8 +91,11 @@ def test_conv2d_matches_torch(be, tile):
     root = str(Path(__file__).resolve().parent.parent)
     env = dict(os.environ, PP_CONV_TILE=tile, PP_TEST_BACKEND=be, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     env["PP_CONV_HALO"] = "0"      # the flat-tile kernels ...
+    env["PP_CONV_KSPLIT"] = "0"
     if tile == "halo":             # ... or the halo-tile kernel for every eligible PP_F32X2 geometry, whatever its size
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
+    if tile == "ksplit":           # ... or the in-work-group split-K kernel for every f16 problem with >= 4 chunks
+        env.update(PP_CONV_TILE="large", PP_CONV_KSPLIT="force")
     r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
@@ -147,6 +162,24 @@ def _run_case(backend, case):
     assert torch.all(buf[..., :4].float().cpu() == 7.0) and torch.all(buf[..., 4 + Cout * groups:].float().cpu() == 7.0)
 
 
+@pytest.mark.parametrize("family", ["flat", "halo", "ksplit"])
+def test_f16_conv_with_f32_output(backend, family, monkeypatch):
+    """f16 operands, fp32 output (the deformable offsets / masks `om`) with a two-activation split, every kernel family."""
+    monkeypatch.setenv("PP_CONV_HALO", "force" if family == "halo" else "0")
+    monkeypatch.setenv("PP_CONV_KSPLIT", "force" if family == "ksplit" else "0")
+    g = torch.Generator().manual_seed(21)
+    N, H, W, C, Cout = 1, 11, 19, 72, 136
+    x = torch.randn(N, H, W, C, generator=g).half()
+    w = torch.randn(Cout, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    spec = ops.make_conv_spec(w, b, torch.float16, padding=1).to(backend)
+    out = torch.empty(N, H, W, Cout, device=backend, dtype=torch.float32)
+    ops.conv2d(spec, [x.to(backend)], out, act="tanh", out_scale=5.0, act2="sigmoid", act_split=96)
+    pre = F.conv2d(x.float().permute(0, 3, 1, 2).double(), w.half().double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    ref = torch.cat([5.0 * torch.tanh(pre[..., :96]), torch.sigmoid(pre[..., 96:])], -1)
+    assert (out.double().cpu() - ref).abs().max().item() < 2e-3
+
+
 @pytest.mark.parametrize("halo", ["0", "force"])
 def test_f32x2_operand_range(backend, halo, monkeypatch):
     """PP_F32X2 at the edge of the f16 range (silent failure for |v| >= 32752).  The low term saturates:
@@ -175,7 +208,7 @@ def test_f32x2_operand_range(backend, halo, monkeypatch):
     assert (out.double().cpu() - ref2).abs().max().item() <= 0.05 + 2e-5 * ref2.abs().max().item()
 
 
-@pytest.mark.parametrize("tile,seed", [("large", 11), ("small", 12), ("xlforce", 13), ("tiny", 14), ("halo", 15)])
+@pytest.mark.parametrize("tile,seed", [("large", 11), ("small", 12), ("xlforce", 13), ("tiny", 14), ("halo", 15), ("ksplit", 16)])
 def test_conv2d_random_geometries_under_emulation(tile, seed):
     import os
     import subprocess
@@ -184,9 +217,11 @@ def test_conv2d_random_geometries_under_emulation(tile, seed):
 
     root = str(Path(__file__).resolve().parent.parent)
     env = dict(os.environ, PP_CONV_TILE=tile, PP_TEST_BACKEND="emu", PP_CONV_RANDOM=str(seed), PP_CONV_HALO="0",
-               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+               PP_CONV_KSPLIT="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     if tile == "halo":
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
+    if tile == "ksplit":
+        env.update(PP_CONV_TILE="large", PP_CONV_KSPLIT="force")
     r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 

@@ -49,7 +49,7 @@ def test_loader_is_strict(tmp_path):
 class _Dummy:
     built = 0
 
-    def __init__(self, sd, device):
+    def __init__(self, sd, device, dtype=None):
         _Dummy.built += 1
         self.n = len(sd)
 

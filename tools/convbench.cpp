@@ -46,6 +46,11 @@ static const std::vector<Shape> SHAPES = {
     {"fc1_f16", PP_F16, 1, 1, 29160, {512}, 1960, 1, 1, 0, 0},
     {"qkv_f16", PP_F16, 1, 1, 27540, {512}, 1536, 1, 1, 0, 0},
     {"rfc_step_f16", PP_F16, 2, 45, 80, {128, 128}, 128, 3, 3, 1, 1},
+    {"rfc_off0_f16", PP_F16, 2, 45, 80, {128, 128, 128}, 128, 3, 3, 1, 1},
+    {"rfc_bb2_f16", PP_F16, 2, 45, 80, {128}, 128, 3, 3, 1, 1},
+    {"rfc_dcn_f16", PP_F16, 2, 45, 80, {2304}, 128, 1, 1, 0, 0},
+    {"featprop_bb2_f16", PP_F16, 14, 90, 160, {128}, 128, 3, 3, 1, 1},
+    {"dec_3x3_128_128_f16", PP_F16, 11, 180, 320, {128}, 128, 3, 3, 1, 1},
 };
 
 static uint32_t rng_state = 12345u;
