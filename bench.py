@@ -189,16 +189,21 @@ def main():
     frames_u8, fm, md = make_inputs(T, CFG["H"], CFG["W"], CFG["mask_dilates"], CFG["flow_mask_dilates"], seed=1234)
     cfg = pipeline.ProPainterConfig(CFG["ref_stride"], CFG["neighbor_length"], CFG["subvideo_length"], CFG["raft_iter"],
                                     "enable", T, dev, (CFG["W"], CFG["H"]))
-    fr_d, fm_d, md_d = torch.from_numpy(frames_u8).to(dev), torch.from_numpy(fm).to(dev), torch.from_numpy(md).to(dev)
+    fm_d, md_d = torch.from_numpy(fm).to(dev), torch.from_numpy(md).to(dev)
 
     if world > 1:
         from comfyui_propainter_nodes_amd import distributed as D
 
         backend = D.GpuBackend(models, cfg)
+        # a rank uploads and keeps only the frames it needs (its sub-videos + 10-frame halos); masks are clip-long
+        lo, hi = D.frames_needed(D.ShardPlan(T, cfg.subvideo_length, world, rank))
+        fr_d = D.Slab(lo, torch.from_numpy(frames_u8[lo:hi]).to(dev))
 
         def step():
             return D.run_distributed(backend, cfg, fr_d, fm_d, md_d)
     else:
+        fr_d = torch.from_numpy(frames_u8).to(dev)
+
         def step():
             return pipeline.run_inpainting(models, fr_d, fm_d, md_d, cfg, to_host=False)
 

@@ -63,9 +63,11 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
   const int xoff_h = (xj ^ swz(xrow0)) << 4;
   const int xoff_l = ((xj + 4) ^ swz(xrow0)) << 4;
 
-  // per pass: pixel index of tap (0,0) and its (y, x), packed to 16 bits each
+  // per pass: pixel index of tap (0,0) and its (y, x).  (They used to share one register as two 16-bit halves: a
+  // temporal convolution of flow completion sees a clip as a [T] x [2 h w] image whose width passes 32767 from
+  // 360x640 frames on, and x wrapped negative -- every tap of those pixels was treated as padding.)
   int64_t prow[XPASS];
-  int pyx[XPASS];
+  int py0[XPASS], px0[XPASS];
 #pragma unroll
   for (int i = 0; i < XPASS; ++i) {
     const int r = xrow0 + i * XROWS;
@@ -77,7 +79,8 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
     const int n = (int)(t / p.Ho);
     const int y0 = ho * p.sh - p.ph, x0 = wo * p.sw - p.pw;
     prow[i] = (int64_t)n * p.H * p.W + (int64_t)y0 * p.W + x0;
-    pyx[i] = (int)(((unsigned)y0 << 16) | ((unsigned)x0 & 0xffffu));
+    py0[i] = y0;
+    px0[i] = x0;
   }
   const float* wbase = reinterpret_cast<const float*>(p.weight) + (int64_t)z * p.w_zoff;
   const float* wrow[WPASS];
@@ -136,13 +139,13 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
     int okbits = 0;
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
-      const int y = (pyx[i] >> 16) + dy, x = (int)(short)(pyx[i] & 0xffff) + dx;
+      const int y = py0[i] + dy, x = px0[i] + dx;
       bool ok = true;
       int64_t pix;
       if (p.pad_mode == PP_PAD_REPLICATE) {
         const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
         const int xc = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
-        pix = prow[i] + (int64_t)(yc - (pyx[i] >> 16)) * p.W + (xc - (int)(short)(pyx[i] & 0xffff));
+        pix = prow[i] + (int64_t)(yc - py0[i]) * p.W + (xc - px0[i]);
       } else {
         ok = ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
         pix = prow[i] + tapoff;

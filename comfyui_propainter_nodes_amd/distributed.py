@@ -6,24 +6,26 @@ The reference already cuts a long clip into sub-videos of `subvideo_length` fram
 shards: rank r owns a contiguous run of sub-video chunks, i.e. frames [F0, F1).  Per rank:
 
   A  RAFT on the frame pairs it owns
-  x0 all_gather of the raw RAFT flows at the seams (5 per side: the flow-completion halos)
+  x0 raw RAFT flows at the seams (5 per side: the flow-completion halos)            -- peer to peer
   A' flow completion of its chunks
-  x1 all_gather of the completed flows                       (RCCL over xGMI / gloo in tests)
-  B  image propagation of its chunks (+10-frame halo from x1), blend, encoder on its frames
-  x2 all_gather of encoder features + updated masks
-  C  feature propagation + transformer + decoder for the windows centred in [F0, F1)
-  x3 all_gather of the window outputs that land on frames owned by a neighbour (seam windows)
+  x1 completed flows at the seams (10 per side: image-propagation halos)            -- peer to peer
+  B  image propagation of its chunks, blend, encoder on its frames
+  x2 encoder features + updated masks of the frames its windows read (+-45 frames)  -- peer to peer
+  C  feature propagation + transformer + decoder for the windows centred in [F0, F1), on a clip state over
+     [F0-45, F1+45) only
+  x3 the window outputs that land on frames owned by a neighbour (seam windows)     -- peer to peer
   D  uint8 compose of its own frames in GLOBAL window order (the blend is order dependent)
-  x4 all_gather of the composed frames
+  x4 all_gather of the composed uint8 frames (every rank returns the clip)
+A rank holds and uploads only the frames it needs (`frames_needed`: its own +-10); masks are clip-long host plumbing.
 
 Because chunk boundaries, halos and window schedule are exactly the single-GPU ones, the sharded
 result is identical to the single-process result.  The driver is written against a small backend
 protocol so that the orchestration can be tested on CPU (gloo, world_size 2) with a toy backend and
 on one GPU with N in-process virtual ranks; `GpuBackend` is the real thing.
 
-The collectives gather whole per-rank slabs (affordable: 640 frames x 3.7 MB = 2.4 GB per exchange,
-xGMI is point-to-point so every peer pair moves its slice concurrently); trimming them to the seams
-is a bandwidth optimisation that does not change results.
+xGMI is point to point, so the seams are exchanged as grouped send / receive pairs between the ranks that share them
+(`dist.batch_isend_irecv`; at the defaults 5 + 10 flows and 45 frames of encoder features per side: ~0.4 GB per rank and
+clip instead of the 2 x 2.4 GB an all_gather of whole per-rank slabs delivers to every rank of an 8-GPU job).
 """
 from __future__ import annotations
 
@@ -142,7 +144,10 @@ class GpuBackend:
 
 
 # ------------------------------------------------------------------------------------------------
-# the sharded driver (a generator: yields tensors to all_gather, receives the per-rank list)
+# the sharded driver (a generator: it yields communication requests and receives their results)
+#   yield tensor                      -> all_gather: the list of every rank's tensor (same shape everywhere)
+#   yield ("p2p", sends, recvs)       -> neighbour exchange: sends {peer: tensor}, recvs {peer: (shape, dtype)};
+#                                        the value sent back is {peer: tensor}
 # ------------------------------------------------------------------------------------------------
 def _pad_first(t: torch.Tensor, n: int) -> torch.Tensor:
     if t.shape[0] == n:
@@ -151,104 +156,154 @@ def _pad_first(t: torch.Tensor, n: int) -> torch.Tensor:
     return torch.cat([t, pad], 0)
 
 
+class Slab:
+    """Rows [lo, lo + len) of a clip-long tensor (a rank only holds the frames it needs: its own plus halos)."""
+
+    def __init__(self, lo: int, t: torch.Tensor):
+        self.lo, self.t = lo, t
+
+    @property
+    def hi(self) -> int:
+        return self.lo + self.t.shape[0]
+
+    def rows(self, a: int, b: int) -> torch.Tensor:
+        if a < self.lo or b > self.hi:
+            raise IndexError(f"rows [{a},{b}) outside the slab [{self.lo},{self.hi})")
+        return self.t[a - self.lo:b - self.lo]
+
+
+def _interval(rng: tuple[int, int], halo: int, n: int) -> tuple[int, int]:
+    a, b = rng
+    return (a, a) if b <= a else (max(0, a - halo), min(n, b + halo))
+
+
+def _halo_exchange(own: torch.Tensor, ranges: list[tuple[int, int]], rank: int, need: list[tuple[int, int]]):
+    """Sub-generator: `own` holds this rank's rows `ranges[rank]` of a clip-long tensor (row = dim 0); every rank r needs
+    the rows `need[r]` (an interval containing its own range).  Each rank sends a peer exactly the part of its rows the
+    peer needs -- for halos of a few frames that is the two neighbours only -- and returns a Slab over `need[rank]`."""
+    a, b = ranges[rank]
+    lo, hi = need[rank]
+    sends, recvs = {}, {}
+    for r, (ra, rb) in enumerate(ranges):
+        if r == rank:
+            continue
+        x, y = max(a, need[r][0]), min(b, need[r][1])         # my rows that peer r needs
+        if y > x:
+            sends[r] = own[x - a:y - a].contiguous()
+        x, y = max(ra, lo), min(rb, hi)                       # peer r's rows that I need
+        if y > x:
+            recvs[r] = ((y - x,) + tuple(own.shape[1:]), own.dtype)
+    got = yield ("p2p", sends, recvs)
+    buf = torch.empty((hi - lo,) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device)
+    if b > a:
+        buf[a - lo:b - lo] = own
+    for r, (ra, rb) in enumerate(ranges):
+        if r in recvs:
+            x, y = max(ra, lo), min(rb, hi)
+            buf[x - lo:y - lo] = got[r]
+    return Slab(lo, buf)
+
+
 def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8):
-    """Generator implementing phases A..D for one rank. `yield tensor` = all_gather (same shape on every rank);
-    the value sent back is the list of every rank's tensor.  Returns the full composed clip (uint8 [T,H,W,3])."""
+    """Generator implementing phases A..D for one rank.  `frames_u8` is the whole clip [T,H,W,3] or a `Slab` holding at
+    least `frames_needed(plan)`; the masks are clip-long (they are replicated host plumbing, 0.23 MB per frame).
+    Returns the full composed clip (uint8 [T,H,W,3]) on every rank."""
     T = plan.T
     F0, F1 = plan.frames
-    frames_all = backend.to_frames(frames_u8)
-    # ---- A: RAFT on the owned pairs, seam exchange of the raw flows, flow completion of the owned chunks --------
-    # (RAFT is per-pair independent -- tests/test_raft.py -- so a neighbour's flows are the ones this rank would
-    #  have computed itself: the 5-flow completion halos are exchanged instead of recomputed)
     fa, fb = plan.flows
-    HAL = 5
-    dev = frames_all.device
-    zero_flows = torch.zeros((2, 0) + tuple(frames_all.shape[1:3]) + (2,), device=dev)
-    raw = backend.raft(frames_all[fa:fb + 1]) if fb > fa else zero_flows
-    k = min(HAL, fb - fa)
-    # x0: the first / last (up to) 5 raw flows of every rank
-    g_seam = yield torch.cat([_pad_first(raw[:, :k].transpose(0, 1), HAL),
-                              _pad_first(raw[:, fb - fa - k:].transpose(0, 1), HAL)], 0)
-
-    def raw_flow(g: int) -> torch.Tensor:        # global flow index -> [2,H,W,2]
-        if fa <= g < fb:
-            return raw[:, g - fa]
-        for r, (a, b) in enumerate(plan.flow_ranges):
-            if a <= g < b:
-                kr = min(HAL, b - a)
-                if g - a < kr:
-                    return g_seam[r][g - a]
-                if b - g <= kr:
-                    return g_seam[r][HAL + (g - (b - kr))]
-                raise AssertionError(f"flow {g} is not inside a seam of rank {r}")
-        raise IndexError(g)
-
-    max_flows = max(b - a for a, b in plan.flow_ranges)
+    nflow = T - 1
+    fr = frames_u8 if isinstance(frames_u8, Slab) else Slab(0, frames_u8)
+    f_lo, f_hi = frames_needed(plan)
+    dev = fr.t.device
+    frames_loc = Slab(f_lo, backend.to_frames(fr.rows(f_lo, f_hi))) if f_hi > f_lo else Slab(f_lo, fr.t[0:0].float())
+    hw = tuple(fr.t.shape[1:3])
+    # ---- A: RAFT on the owned pairs; x0: the 5-flow completion halos come from the neighbours (RAFT is per-pair
+    # independent -- tests/test_raft.py -- so a neighbour's flows are the ones this rank would have computed itself)
+    raw = backend.raft(frames_loc.rows(fa, fb + 1)) if fb > fa else torch.zeros((2, 0) + hw + (2,), device=dev)
+    need0 = [_interval(r, 5, nflow) for r in plan.flow_ranges]
+    raw_s = yield from _halo_exchange(raw.transpose(0, 1), plan.flow_ranges, plan.rank, need0)   # rows = flows, [n,2,H,W,2]
     own = []
     for f, e_own, s, e in plan.flow_chunks():
-        left = [raw_flow(g) for g in range(s, min(e, fa))]
-        right = [raw_flow(g) for g in range(max(s, fb), e)]
-        mid = raw[:, max(s, fa) - fa:min(e, fb) - fa]
-        gt = torch.cat(([torch.stack(left, 1)] if left else []) + [mid] + ([torch.stack(right, 1)] if right else []), 1)
+        gt = raw_s.rows(s, e).transpose(0, 1).contiguous()
         sub = backend.complete(gt, flow_masks_u8[s:e + 1])
         own.append(sub[:, f - s:e_own - s])
-    flow_shape = (2, 0) + tuple(frames_all.shape[1:3]) + (2,)
-    own_flows = torch.cat(own, 1) if own else torch.zeros(flow_shape, device=frames_all.device)
-    # x1: completed flows of every rank
-    gathered = yield _pad_first(own_flows.transpose(0, 1), max_flows)
-    parts = [g[:b - a].transpose(0, 1) for g, (a, b) in zip(gathered, plan.flow_ranges)]
-    pred = torch.cat(parts, 1).contiguous()                       # [2,T-1,H,W,2]
+    own_flows = torch.cat(own, 1) if own else torch.zeros((2, 0) + hw + (2,), device=dev)
+    # x1: completed flows, 10 flows either side (image propagation halos; the windows' neighbour frames lie inside)
+    def flows_for_frames(r):          # completed flows read by rank r's image-propagation chunks (a rank may own frames
+        ch = plan.frame_chunks(r)     #  but no flow: the last frame of the clip)
+        a = plan.flow_ranges[r][0]
+        return (min(c[2] for c in ch), max(c[3] for c in ch) - 1) if ch else (a, a)
+
+    need1 = [flows_for_frames(r) for r in range(plan.world)]
+    pred_s = yield from _halo_exchange(own_flows.transpose(0, 1), plan.flow_ranges, plan.rank, need1)
     # ---- B: image propagation of the owned chunks, blend + encoder on the owned frames ---------------
-    max_frames = max(b - a for a, b in plan.frame_ranges)
     props, upds = [], []
     for f, e_own, s, e in plan.frame_chunks():
-        p, m = backend.img_prop(frames_all[s:e], masks_dilated_u8[s:e], pred[:, s:e - 1])
+        pr = pred_s.rows(s, e - 1).transpose(0, 1)
+        p, m = backend.img_prop(frames_loc.rows(s, e), masks_dilated_u8[s:e], pr)
         props.append(p[f - s:e_own - s])
         upds.append(m[f - s:e_own - s])
-    if props:
-        prop, upd = torch.cat(props, 0), torch.cat(upds, 0)
-        enc_own = backend.encode(frames_all[F0:F1], prop, masks_dilated_u8[F0:F1], upd)
-    else:
-        upd = masks_dilated_u8[0:0]
-        enc_own = None
-    # x2: encoder features + updated masks of every rank
-    enc_shape = yield torch.tensor(list(enc_own.shape[1:]) if enc_own is not None else [0, 0, 0], device=frames_all.device)
-    eshape = [int(v) for v in max(enc_shape, key=lambda t: int(t.sum()))]
-    if enc_own is None:
-        enc_own = torch.zeros([0] + eshape, device=frames_all.device, dtype=torch.float16)
-    g_enc = yield _pad_first(enc_own, max_frames)
-    g_upd = yield _pad_first(upd, max_frames)
-    enc = torch.cat([g[:b - a] for g, (a, b) in zip(g_enc, plan.frame_ranges)], 0)
-    upd_all = torch.cat([g[:b - a] for g, (a, b) in zip(g_upd, plan.frame_ranges)], 0)
-    st = backend.make_state(enc, pred, masks_dilated_u8, upd_all)
-    # ---- C: the windows centred in the owned frames ------------------------------------------------------
     schedule = window_schedule(config)
     ns = config.neighbor_length // 2
     centers = [wi * ns for wi in range(len(schedule))]
+
+    def frames_of_windows(rng):       # frames read by the windows centred in `rng` (neighbours + references)
+        ids = [i for wi, c in enumerate(centers) if rng[0] <= c < rng[1] for i in schedule[wi][0] + schedule[wi][1]]
+        return (min(ids + [rng[0]]), max(ids + [rng[1] - 1]) + 1) if rng[1] > rng[0] else (rng[0], rng[0])
+
+    need2 = [frames_of_windows(r) for r in plan.frame_ranges]
+    if props:
+        prop, upd = torch.cat(props, 0), torch.cat(upds, 0)
+        enc_own = backend.encode(frames_loc.rows(F0, F1), prop, masks_dilated_u8[F0:F1], upd)
+    else:
+        upd = masks_dilated_u8[0:0]
+        enc_own = None
+    # the encoder's output geometry is only known to ranks that ran it: agree on it (3 integers)
+    enc_shape = yield torch.tensor(list(enc_own.shape[1:]) if enc_own is not None else [0, 0, 0], device=dev)
+    eshape = [int(v) for v in max(enc_shape, key=lambda t: int(t.sum()))]
+    if enc_own is None:
+        enc_own = torch.zeros([0] + eshape, device=dev, dtype=torch.float16)
+    # x2: encoder features + updated masks of the frames this rank's windows read (+-45 frames at the defaults)
+    enc_s = yield from _halo_exchange(enc_own, plan.frame_ranges, plan.rank, need2)
+    upd_s = yield from _halo_exchange(upd, plan.frame_ranges, plan.rank, need2)
+    S0, S1 = need2[plan.rank]
+    # ---- C: the windows centred in the owned frames, on a clip state over [S0, S1) only --------------------------
     mine = [wi for wi, f in enumerate(centers) if F0 <= f < F1]
-    lp = backend.propagate_windows(st, [schedule[wi][0] for wi in mine]) if mine else []
-    preds = {wi: backend.forward_window(st, schedule[wi][0], schedule[wi][1], lp[j]) for j, wi in enumerate(mine)}
-    # x3: window outputs that land on frames of another rank
-    exports: list[list[tuple[int, int]]] = [[] for _ in range(plan.world)]
+    preds = {}
+    if mine:
+        flows_loc = torch.zeros((2, max(S1 - S0 - 1, 0)) + hw + (2,), device=dev)
+        x, y = max(S0, pred_s.lo), min(S1 - 1, pred_s.hi)        # flows beyond the halos are only between reference
+        if y > x:                                                #  frames and are never read
+            flows_loc[:, x - S0:y - S0] = pred_s.rows(x, y).transpose(0, 1)
+        st = backend.make_state(enc_s.t, flows_loc, masks_dilated_u8[S0:S1].contiguous(), upd_s.t)
+        loc = {wi: ([i - S0 for i in schedule[wi][0]], [i - S0 for i in schedule[wi][1]]) for wi in mine}
+        lp = backend.propagate_windows(st, [loc[wi][0] for wi in mine])
+        preds = {wi: backend.forward_window(st, loc[wi][0], loc[wi][1], lp[j]) for j, wi in enumerate(mine)}
+    # x3: window outputs that land on frames of another rank (the seam windows), peer to peer
+    exports: list[dict[int, list[tuple[int, int]]]] = [dict() for _ in range(plan.world)]   # [src][dst] -> [(wi, idx)]
     for wi, (nb, _) in enumerate(schedule):
-        r = plan.owner_of_frame(centers[wi])
-        exports[r] += [(wi, idx) for idx in nb if plan.owner_of_frame(idx) != r]
-    max_exp = max(1, max(len(e) for e in exports))
-    H, W = frames_all.shape[1:3]
+        src = plan.owner_of_frame(centers[wi])
+        for idx in nb:
+            dst = plan.owner_of_frame(idx)
+            if dst != src:
+                exports[src].setdefault(dst, []).append((wi, idx))
+    H, W = hw
     pred_tail = tuple(next(iter(preds.values())).shape[1:]) if preds else (H, W, 4)
-    tail_g = yield torch.tensor(list(pred_tail), device=frames_all.device)
+    tail_g = yield torch.tensor(list(pred_tail), device=dev)
     pred_tail = tuple(int(v) for v in max(tail_g, key=lambda t: int(t.sum())))
-    exp = torch.zeros((max_exp,) + pred_tail, device=frames_all.device, dtype=torch.float16)
-    for j, (wi, idx) in enumerate(exports[plan.rank]):
-        exp[j] = preds[wi][schedule[wi][0].index(idx)]
-    g_exp = yield exp
+    sends = {dst: torch.stack([preds[wi][schedule[wi][0].index(idx)] for wi, idx in lst], 0)
+             for dst, lst in exports[plan.rank].items()}
+    recvs = {src: ((len(exports[src][plan.rank]),) + pred_tail, torch.float16)
+             for src in range(plan.world) if src != plan.rank and plan.rank in exports[src]}
+    got = yield ("p2p", sends, recvs)
     foreign = {}
-    for r, lst in enumerate(exports):
-        for j, (wi, idx) in enumerate(lst):
-            if F0 <= idx < F1:
-                foreign[(wi, idx)] = g_exp[r][j]
+    for src, t in got.items():
+        for j, key in enumerate(exports[src][plan.rank]):
+            foreign[key] = t[j]
     # ---- D: compose the owned frames in global window order -----------------------------------------------
-    comp = torch.zeros((T,) + tuple(frames_u8.shape[1:]), dtype=torch.uint8, device=frames_all.device)
+    comp = torch.zeros((F1 - F0,) + hw + (3,), dtype=torch.uint8, device=dev)
+    orig = fr.rows(F0, F1).contiguous()
+    md_own = masks_dilated_u8[F0:F1].contiguous()
     seen = [False] * T
     for wi, (nb, _) in enumerate(schedule):
         ids = [idx for idx in nb if F0 <= idx < F1]
@@ -258,34 +313,59 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
             p = torch.stack([preds[wi][nb.index(idx)] for idx in ids], 0)
         else:
             p = torch.stack([foreign[(wi, idx)] for idx in ids], 0)
-        backend.compose(comp, p, ids, [0 if seen[i] else 1 for i in ids], masks_dilated_u8, frames_u8)
+        backend.compose(comp, p, [i - F0 for i in ids], [0 if seen[i] else 1 for i in ids], md_own, orig)
         for i in ids:
             seen[i] = True
-    g_comp = yield _pad_first(comp[F0:F1], max_frames)
+    # x4: every rank returns the whole composed clip (uint8 frames: 0.7 MB each)
+    max_frames = max(b - a for a, b in plan.frame_ranges)
+    g_comp = yield _pad_first(comp, max_frames)
     return torch.cat([g[:b - a] for g, (a, b) in zip(g_comp, plan.frame_ranges)], 0)
+
+
+def frames_needed(plan: ShardPlan) -> tuple[int, int]:
+    """Frames a rank has to hold: its RAFT pairs and its image-propagation chunks with their 10-frame halos."""
+    F0, F1 = plan.frames
+    fa, fb = plan.flows
+    if F1 <= F0:
+        return (F0, F0)
+    return (max(0, min(F0 - 10, fa)), min(plan.T, max(F1 + 10, fb + 1)))
 
 
 # ------------------------------------------------------------------------------------------------
 # runners
 # ------------------------------------------------------------------------------------------------
 def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8, group=None):
-    """One rank of a torch.distributed job (backend "nccl" = RCCL on the MI355X, "gloo" in CPU tests)."""
+    """One rank of a torch.distributed job (backend "nccl" = RCCL on the MI355X, "gloo" in CPU tests).  all_gather for the
+    two whole-clip exchanges, grouped point-to-point sends / receives (xGMI is point to point: a seam travels over the one
+    link between the two neighbours) for the halos."""
     import torch.distributed as dist
 
     plan = ShardPlan(config.video_length, config.subvideo_length, dist.get_world_size(group), dist.get_rank(group))
     gen = run_rank(backend, plan, config, frames_u8, flow_masks_u8, masks_dilated_u8)
-    via_host = dist.get_backend(group) == "gloo"  # gloo has no device all_gather: stage through the host (tests only)
+    via_host = dist.get_backend(group) == "gloo"  # gloo moves host memory: stage through the host (tests only)
+    dev = (frames_u8.t if isinstance(frames_u8, Slab) else frames_u8).device
+
+    def wire(t):
+        return t.cpu() if via_host and t.is_cuda else t.contiguous()
+
     try:
         t = next(gen)
         while True:
-            if via_host and t.is_cuda:
-                th = t.cpu()
+            if isinstance(t, tuple):
+                _, sends, recvs = t
+                bufs = {peer: torch.empty(shape, dtype=dtype, device="cpu" if via_host else dev)
+                        for peer, (shape, dtype) in recvs.items()}
+                p2p = [dist.P2POp(dist.irecv, buf, peer, group) for peer, buf in bufs.items()]
+                p2p += [dist.P2POp(dist.isend, wire(ten), peer, group) for peer, ten in sends.items()]
+                if p2p:
+                    for req in dist.batch_isend_irecv(p2p):
+                        req.wait()
+                out = {peer: buf.to(dev) for peer, buf in bufs.items()}
+            else:
+                th = wire(t)
                 outh = [torch.empty_like(th) for _ in range(plan.world)]
                 dist.all_gather(outh, th, group=group)
                 out = [o.to(t.device) for o in outh]
-            else:
-                out = [torch.empty_like(t) for _ in range(plan.world)]
-                dist.all_gather(out, t.contiguous(), group=group)
             t = gen.send(out)
     except StopIteration as stop:
         return stop.value
@@ -300,8 +380,18 @@ def run_simulated(make_backend, world: int, config: ProPainterConfig, frames_u8,
     while any(r is None for r in results):
         nxt = []
         for r, g in enumerate(gens):
+            if isinstance(vals[r], tuple):      # neighbour exchange: what every peer addressed to rank r
+                _, _, recvs = vals[r]
+                reply = {}
+                for src, (shape, dtype) in recvs.items():
+                    t = vals[src][1][r]
+                    assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (src, r, tuple(t.shape), shape)
+                    reply[src] = t.clone()
+                assert all(r in vals[dst][2] for dst in vals[r][1]), "a send without a matching receive"
+            else:
+                reply = [v.clone() for v in vals]
             try:
-                nxt.append(g.send([v.clone() for v in vals]))
+                nxt.append(g.send(reply))
             except StopIteration as stop:
                 results[r] = stop.value
                 nxt.append(None)

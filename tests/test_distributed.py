@@ -2,8 +2,10 @@
 
 CPU: the real driver (comfyui_propainter_nodes_amd/distributed.py) over torch.distributed/gloo with world_size 2 and 3,
 stage functions replaced by a toy backend; the sharded result must equal the single-rank result exactly.
-GPU: the same driver with the real MI355X backend and 3 in-process virtual ranks must reproduce the
-single-GPU pipeline bit for bit on the chunked fixture."""
+GPU: the same driver with the real MI355X backend (in-process virtual ranks, and two real processes over gloo) must
+reproduce the single-GPU pipeline on the chunked fixture: bit for bit when the convolution kernel selection is pinned
+(PP_CONV_KSPLIT=0: the in-work-group split-K kernel is chosen by problem size, a rank's smaller batches can select it where
+the single-GPU run does not, and its partial sums add in another order), within 1 LSB of the uint8 frames otherwise."""
 import os
 from pathlib import Path
 
@@ -105,9 +107,24 @@ def test_sharded_equals_single_rank_edge_cases(world, T, nl, rs, sv):
         assert got.shape == ref.shape and torch.equal(got, ref), f"virtual rank {r} differs"
 
 
+def _assert_same_frames(got, single, exact, what):
+    if exact:
+        assert torch.equal(got, single), what
+    else:
+        d = (got.int() - single.int()).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, (what, int(d.max()), float((d > 0).float().mean()))
+
+
 @pytest.mark.gpu
-def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib):
+@pytest.mark.parametrize("pinned", [True, False])
+def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib, monkeypatch, pinned):
     from comfyui_propainter_nodes_amd import weights
+
+    if pinned:
+        monkeypatch.setenv("PP_CONV_KSPLIT", "0")
+    # (virtual ranks share one model object: its captured recurrence graphs hand out static buffers, which two ranks
+    #  advancing in lock-step would overwrite for each other -- a real rank has its own process and models)
+    monkeypatch.setenv("PP_GRAPHS", "0")
 
     g = np.load(GOLD / "e2e_chunked.npz")
     T, H, W, iters, nl, rs, sv, _, _, seed = [int(v) for v in g["params"]]
@@ -119,7 +136,7 @@ def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib):
     for world in (2, 3):
         res = D.run_simulated(lambda r: D.GpuBackend(models, cfg), world, cfg, fr, fm, md)
         for r in range(world):
-            assert torch.equal(res[r].cpu(), single), f"world {world} rank {r}"
+            _assert_same_frames(res[r].cpu(), single, pinned, f"world {world} rank {r}")
 
 
 def _gpu_worker(rank, world, port, out_dir):
@@ -148,12 +165,15 @@ def _gpu_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_two_processes_with_the_gpu_backend_match_single_process(hip_lib, tmp_path):
-    port = 29500 + (os.getpid() * 3 + 11) % 2000
+@pytest.mark.parametrize("pinned", [True, False])
+def test_two_processes_with_the_gpu_backend_match_single_process(hip_lib, tmp_path, monkeypatch, pinned):
+    if pinned:
+        monkeypatch.setenv("PP_CONV_KSPLIT", "0")  # inherited by the spawned ranks
+    port = 29500 + (os.getpid() * 3 + 11 + int(pinned)) % 2000
     mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     single = torch.load(tmp_path / "single.pt")
     for r in range(2):
-        assert torch.equal(torch.load(tmp_path / f"r{r}.pt"), single), f"rank {r}"
+        _assert_same_frames(torch.load(tmp_path / f"r{r}.pt"), single, pinned, f"rank {r}")
 
 
 @pytest.mark.gpu

@@ -48,11 +48,12 @@ class ToyBackend:
     def forward_window(self, st, nb, refs, local_prop):
         H, W = st["md"].shape[1:]
         ref = st["enc"][refs].sum() if refs else torch.tensor(0.0)
-        val = torch.tanh(local_prop.sum((1, 2, 3)) * 0.3 + 0.01 * ref + 0.001 * torch.tensor(nb, dtype=torch.float32))
+        # (nothing here may depend on absolute frame numbers: a rank works on a clip state over its own frames + halos)
+        val = torch.tanh(local_prop.sum((1, 2, 3)) * 0.3 + 0.01 * ref + 0.001 * torch.arange(len(nb), dtype=torch.float32))
         ramp = torch.linspace(-0.2, 0.2, H * W).view(1, H, W, 1)
         return (val.view(-1, 1, 1, 1) * 0.7 + ramp).expand(-1, H, W, 4).contiguous().half()
 
-    def compose(self, comp, pred, frame_ids, first, md, frames_u8):
+    def compose(self, comp, pred, frame_ids, first, md, frames_u8):   # ids index comp / md / frames_u8 alike
         for j, idx in enumerate(frame_ids):
             p = ((pred[j, ..., :3].float() + 1) / 2 * 255).to(torch.uint8)
             m = md[idx].bool()[..., None]
