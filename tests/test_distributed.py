@@ -112,7 +112,7 @@ def _assert_same_frames(got, single, exact, what):
         assert torch.equal(got, single), what
     else:
         d = (got.int() - single.int()).abs()
-        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, (what, int(d.max()), float((d > 0).float().mean()))
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-2, (what, int(d.max()), float((d > 0).float().mean()))
 
 
 @pytest.mark.gpu
