@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_kernel(const 
     unsigned char* wt = smem + XBYTES + wbuf * WSTAGE;
     const int woff = w_tap * p.chunks_per_tap * 32 + w_sbase + w_rem * 32;
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
+    for (int i = 0; i < WPASS; ++i)
+      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
     w_advance();
   };
 
@@ -149,8 +150,12 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_kernel(const 
     for (int i = 0; i < XPASS; ++i) {
       const bool ok0 = xpix[i] >= 0 && c0 < x_C, ok1 = xpix[i] >= 0 && c0 + 4 < x_C;
       const float* src = ok0 ? x_base + (int64_t)xpix[i] * x_ldc + c0 : x_base;
-      gload16_hidden(xreg[i][0], src);
-      gload16_hidden(xreg[i][1], src + (ok1 ? 4 : 0));
+      if constexpr (!(PP_ABLATE & 2)) {
+        gload16_hidden(xreg[i][0], src);
+        gload16_hidden(xreg[i][1], src + (ok1 ? 4 : 0));
+      } else {
+        asm volatile("" : "=v"(xreg[i][0]), "=v"(xreg[i][1]) : "v"(src), "v"(ok1));
+      }
       okbits |= ((ok0 ? 1 : 0) | (ok1 ? 2 : 0)) << (2 * i);
     }
     xok = okbits;
@@ -374,7 +379,8 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_halo_f16_kernel(const ConvK
     unsigned char* wt = smem + 2 * XSTAGE + wbuf * WSTAGE;
     const int woff = w_tap * p.chunks_per_tap * 32 + w_sbase + w_rem * 32;
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
+    for (int i = 0; i < WPASS; ++i)
+      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
     if (++w_tap == ntaps) {
       w_tap = 0;
       if (++w_rem == w_chunks) {
@@ -397,7 +403,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_halo_f16_kernel(const ConvK
     for (int i = 0; i < XPASS; ++i) {
       const bool ok = xpix[i] >= 0 && c0 < x_C;
       const void* src = ok ? static_cast<const void*>(x_base + (int64_t)xpix[i] * x_ldc + c0) : static_cast<const void*>(pp_zero16);
-      glds16(src, xt + (i * NT + wave * 64) * 16);
+      if constexpr (!(PP_ABLATE & 2)) glds16(src, xt + (i * NT + wave * 64) * 16);
     }
     if (++x_rem == x_chunks) {
       x_rem = 0;
@@ -568,6 +574,9 @@ static bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* g) {
 int launch_halo_split(void* stream, const ConvK& k, int Z) {
   HaloGeom g;
   if (!halo_geometry(k, Z, kHaloMaxRows, &g)) return 1;
+  // (A two-group form -- one 8-wave work-group per CU, two pixel tiles sharing the weight ring, group 1 held half a step
+  // behind group 0 by an extra barrier so that one group's MFMA burst always met the other's loads -- was built, checked
+  // on the MI355X and measured SLOWER: RAFT GRU 1x5 228 vs 277 TF/s, 3x3 256->192 254 vs 320; removed)
   if (k.Cout > 64) {
     const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
     const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
