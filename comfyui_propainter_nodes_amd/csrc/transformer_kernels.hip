@@ -85,12 +85,19 @@ __global__ void __launch_bounds__(256) pool_tokens_kernel(const half_t* __restri
 // ----------------------------------------------------------------------------------------
 // sparse window attention
 //
-// block = (query tile | frame, head, window), 4 waves x 16 queries.  Per 32-key tile:
-//   S^T = K . Q^T   (A = K tile from LDS, B = Q fragment in registers)  -> lane holds the scores of
-//                    ONE query (col = lane&15) against keys {4g+r, 16+4g+r}, g = lane>>4
+// block = (128-query tile | frame, head, window), 4 waves x 32 queries (two groups of 16).  Per 32-key tile:
+//   S^T = K . Q^T   (A = K tile from LDS, B = Q fragments in registers)  -> lane holds the scores of
+//                    ONE query per group (col = lane&15) against keys {4g+r, 16+4g+r}, g = lane>>4
 //   online softmax   lane-local + two xor-shuffles (16, 32) across the 4 lane groups
 //   O^T += V^T . P^T (A = V^T tile from LDS in the same permuted key order, B = P in registers)
-// so the probabilities never leave registers and the per-query statistics stay lane-local.
+// so the probabilities never leave registers and the per-query statistics stay lane-local.  Every K / V^T fragment read
+// from LDS feeds the MFMAs of BOTH query groups (r01: one group per wave, 64-query blocks: twice the fragment reads and
+// twice the key gathers per MFMA).
+// V^T tile: element (d, key) lives at row d, 8-byte key block ((key >> 2) ^ ((d >> 4) & 7)).  The transposing stores of a
+// staged V row (one key, 16 consecutive d per thread, 8 threads per key) then go to 8 different bank groups; un-swizzled,
+// the 8 threads of a key sit 16 rows = 1280 bytes apart, i.e. on ONE bank: an 8-way conflict on each of the 16 scalar
+// stores per thread and tile (r01).  The fragment reads use one row block (dt) per instruction, so the XOR is uniform
+// across a read's lanes and they stay conflict-free.
 // ----------------------------------------------------------------------------------------
 struct AttnK {
   const half_t* qkv;
@@ -106,6 +113,8 @@ struct AttnK {
 constexpr int kWinH = 5, kWinW = 9, kWinTok = 45, kHeads = 4, kHeadDim = 128, kDim = 512;
 constexpr int kKP = kHeadDim + 8;  // K tile row pitch (halves)
 constexpr int kVP = 32 + 8;        // V^T tile row pitch (halves)
+constexpr int kQG = 2;             // 16-query groups per wave
+constexpr int kQBlock = 4 * kQG * 16;
 
 __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
   __shared__ __attribute__((aligned(16))) half_t Ks[32 * kKP];
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
   int nq, nk, qbase, frame = 0;
   if (masked) {
     nq = k.t * kWinTok;
-    qbase = (int)blockIdx.x * 64;
+    qbase = (int)blockIdx.x * kQBlock;
     if (qbase >= nq) return;
     nk = k.nt * per_frame;
   } else {
@@ -133,25 +142,39 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
   const int lane = tid & 63, wave = tid >> 6;
   const int qcol = lane & 15, g = lane >> 4;
 
-  // ---- this lane's query ---------------------------------------------------------------
-  const int ql = qbase + wave * 16 + qcol;
-  const bool qvalid = ql < nq;
-  const int qc = qvalid ? ql : 0;
-  const int qt = masked ? qc / kWinTok : frame;
-  const int qpos = masked ? qc - qt * kWinTok : qc;
-  const int qy = r0 + qpos / kWinW, qx = c0 + qpos % kWinW;
-  const half_t* qptr = k.qkv + ((int64_t)(qt * k.Hp + qy) * k.Wp + qx) * (3 * kDim) + head * kHeadDim;
-  h8 qf[4];
+  // ---- this lane's queries (one per group) -------------------------------------------------
+  bool qvalid[kQG];
+  int qt[kQG], qy[kQG], qx[kQG];
+  h8 qf[kQG][4];
 #pragma unroll
-  for (int dc = 0; dc < 4; ++dc) qf[dc] = *reinterpret_cast<const h8*>(qptr + dc * 32 + g * 8);
+  for (int qi = 0; qi < kQG; ++qi) {
+    const int ql = qbase + (wave * kQG + qi) * 16 + qcol;
+    qvalid[qi] = ql < nq;
+    const int qc = qvalid[qi] ? ql : 0;
+    qt[qi] = masked ? qc / kWinTok : frame;
+    const int qpos = masked ? qc - qt[qi] * kWinTok : qc;
+    qy[qi] = r0 + qpos / kWinW;
+    qx[qi] = c0 + qpos % kWinW;
+    const half_t* qptr = k.qkv + ((int64_t)(qt[qi] * k.Hp + qy[qi]) * k.Wp + qx[qi]) * (3 * kDim) + head * kHeadDim;
+#pragma unroll
+    for (int dc = 0; dc < 4; ++dc) qf[qi][dc] = *reinterpret_cast<const h8*>(qptr + dc * 32 + g * 8);
+  }
 
-  f4 o[8];
+  f4 o[kQG][8];
+  float m_run[kQG], l_run[kQG];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1.0e30f, l_run = 0.f;
+  for (int qi = 0; qi < kQG; ++qi) {
+    m_run[qi] = -1.0e30f;
+    l_run[qi] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[qi][i] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  // a wave whose 32 queries are all past the end still takes part in the staging and the barriers
+  const bool wave_live = qbase + wave * kQG * 16 < nq;
 
   const int kr = tid >> 3;           // key row staged by this thread
   const int dbase = (tid & 7) * 16;  // 16 head-dim values
+  const int vblk = ((kr >> 2) ^ (tid & 7)) * 4 + (kr & 3);  // swizzled key slot of this thread's V^T stores ((d>>4)&7 == tid&7)
 
   for (int kt = 0; kt < nk; kt += 32) {
     // ---- stage K [32][128] and V^T [128][32] ----------------------------------------------
@@ -198,66 +221,84 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
       *reinterpret_cast<h8*>(Ks + kr * kKP + dbase + 8) = kv1;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        Vt[(dbase + e) * kVP + kr] = vv0[e];
-        Vt[(dbase + 8 + e) * kVP + kr] = vv1[e];
+        Vt[(dbase + e) * kVP + vblk] = vv0[e];
+        Vt[(dbase + 8 + e) * kVP + vblk] = vv1[e];
       }
     }
     __syncthreads();
 
-    // ---- S^T = K . Q^T ---------------------------------------------------------------------
-    f4 s0 = f4{0.f, 0.f, 0.f, 0.f}, s1 = f4{0.f, 0.f, 0.f, 0.f};
+    if (wave_live) {
+      // ---- S^T = K . Q^T ---------------------------------------------------------------------
+      f4 s0[kQG], s1[kQG];
 #pragma unroll
-    for (int dc = 0; dc < 4; ++dc) {
-      const h8 a0 = *reinterpret_cast<const h8*>(Ks + qcol * kKP + dc * 32 + g * 8);
-      const h8 a1 = *reinterpret_cast<const h8*>(Ks + (16 + qcol) * kKP + dc * 32 + g * 8);
-      s0 = mfma_16x16x32_f16(a0, qf[dc], s0);
-      s1 = mfma_16x16x32_f16(a1, qf[dc], s1);
-    }
-    float sc[8];
-    float mt = -1.0e30f;
+      for (int qi = 0; qi < kQG; ++qi) s0[qi] = s1[qi] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sc[r] = (kt + 4 * g + r < nk) ? s0[r] * k.scale : -1.0e30f;
-      sc[4 + r] = (kt + 16 + 4 * g + r < nk) ? s1[r] * k.scale : -1.0e30f;
-      mt = fmaxf(mt, fmaxf(sc[r], sc[4 + r]));
-    }
-    mt = fmaxf(mt, shfl_xor(mt, 16));
-    mt = fmaxf(mt, shfl_xor(mt, 32));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __expf(m_run - m_new);
-    float ps = 0.f;
-    h8 pf;
+      for (int dc = 0; dc < 4; ++dc) {
+        const h8 a0 = *reinterpret_cast<const h8*>(Ks + qcol * kKP + dc * 32 + g * 8);
+        const h8 a1 = *reinterpret_cast<const h8*>(Ks + (16 + qcol) * kKP + dc * 32 + g * 8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float p = __expf(sc[i] - m_new);
-      ps += p;
-      pf[i] = (half_t)p;
-    }
-    ps += shfl_xor(ps, 16);
-    ps += shfl_xor(ps, 32);
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-    // ---- O^T = alpha * O^T + V^T . P^T -----------------------------------------------------
+        for (int qi = 0; qi < kQG; ++qi) {
+          s0[qi] = mfma_16x16x32_f16(a0, qf[qi][dc], s0[qi]);
+          s1[qi] = mfma_16x16x32_f16(a1, qf[qi][dc], s1[qi]);
+        }
+      }
+      h8 pf[kQG];
+      float alpha[kQG];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const half_t* vrow = Vt + (dt * 16 + qcol) * kVP;
-      const h4 lo = *reinterpret_cast<const h4*>(vrow + 4 * g);
-      const h4 hi = *reinterpret_cast<const h4*>(vrow + 16 + 4 * g);
-      const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      o[dt] = o[dt] * alpha;
-      o[dt] = mfma_16x16x32_f16(a, pf, o[dt]);
+      for (int qi = 0; qi < kQG; ++qi) {
+        float sc[8];
+        float mt = -1.0e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[r] = (kt + 4 * g + r < nk) ? s0[qi][r] * k.scale : -1.0e30f;
+          sc[4 + r] = (kt + 16 + 4 * g + r < nk) ? s1[qi][r] * k.scale : -1.0e30f;
+          mt = fmaxf(mt, fmaxf(sc[r], sc[4 + r]));
+        }
+        mt = fmaxf(mt, shfl_xor(mt, 16));
+        mt = fmaxf(mt, shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run[qi], mt);
+        alpha[qi] = __expf(m_run[qi] - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float pv = __expf(sc[i] - m_new);
+          ps += pv;
+          pf[qi][i] = (half_t)pv;
+        }
+        ps += shfl_xor(ps, 16);
+        ps += shfl_xor(ps, 32);
+        l_run[qi] = l_run[qi] * alpha[qi] + ps;
+        m_run[qi] = m_new;
+      }
+      // ---- O^T = alpha * O^T + V^T . P^T -----------------------------------------------------
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const half_t* vrow = Vt + (dt * 16 + qcol) * kVP;  // rows d = dt*16 + qcol: (d >> 4) & 7 == dt
+        const h4 lo = *reinterpret_cast<const h4*>(vrow + 4 * (g ^ dt));
+        const h4 hi = *reinterpret_cast<const h4*>(vrow + 4 * ((4 + g) ^ dt));
+        const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int qi = 0; qi < kQG; ++qi) {
+          o[qi][dt] = o[qi][dt] * alpha[qi];
+          o[qi][dt] = mfma_16x16x32_f16(a, pf[qi], o[qi][dt]);
+        }
+      }
     }
     __syncthreads();
   }
 
   // ---- normalise and scatter back to the unpadded token grid -------------------------------
-  if (!qvalid || qy >= k.fh || qx >= k.fw) return;
-  const float inv = 1.f / l_run;
-  half_t* dst = k.out + ((int64_t)(qt * k.fh + qy) * k.fw + qx) * kDim + head * kHeadDim;
 #pragma unroll
-  for (int dt = 0; dt < 8; ++dt) {
-    h4 v = {(half_t)(o[dt][0] * inv), (half_t)(o[dt][1] * inv), (half_t)(o[dt][2] * inv), (half_t)(o[dt][3] * inv)};
-    *reinterpret_cast<h4*>(dst + dt * 16 + 4 * g) = v;
+  for (int qi = 0; qi < kQG; ++qi) {
+    if (!qvalid[qi] || qy[qi] >= k.fh || qx[qi] >= k.fw) continue;
+    const float inv = 1.f / l_run[qi];
+    half_t* dst = k.out + ((int64_t)(qt[qi] * k.fh + qy[qi]) * k.fw + qx[qi]) * kDim + head * kHeadDim;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      h4 v = {(half_t)(o[qi][dt][0] * inv), (half_t)(o[qi][dt][1] * inv), (half_t)(o[qi][dt][2] * inv),
+              (half_t)(o[qi][dt][3] * inv)};
+      *reinterpret_cast<h4*>(dst + dt * 16 + 4 * g) = v;
+    }
   }
 }
 

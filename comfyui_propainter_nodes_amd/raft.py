@@ -185,7 +185,10 @@ class RaftFlow:
             nxt = torch.empty(P, hw, ph, pw, device=dev)
             ops.avgpool2x2(pyr[-1].view(P * hw, pyr[-1].shape[2], pyr[-1].shape[3]), nxt.view(P * hw, ph, pw))
             pyr.append(nxt)
-        corr = torch.empty(P, h, w, 324, device=dev)
+        # 324 lookup channels at a pitch of 352 floats: every 32-channel chunk (128 bytes) the motion encoder's first
+        # convolution gathers then starts on a cache-line boundary (at pitch 324 each chunk straddled two lines: that 1x1
+        # convolution ran at 120 TF/s where its neighbours reach 250-300)
+        corr = torch.empty(P, h, w, 352, device=dev)[..., :324]
         cor1 = torch.empty(P, h, w, 256, device=dev)
         cf = torch.empty(P, h, w, 256, device=dev)       # cor (192) | flo (64)
         fcols = torch.empty(P, h, w, self.f1_kpad, device=dev)

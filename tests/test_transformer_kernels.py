@@ -64,12 +64,16 @@ def test_fold_unfold_roundtrip_against_torch(backend):
     _close(un, ref)
 
 
-@pytest.mark.parametrize("fh,fw", [(11, 12), (5, 18)])
-def test_window_attention_matches_oracle(backend, fh, fw):
-    """Masked + unmasked windows, window padding, circular rolled neighbours and pooled tokens."""
+@pytest.mark.parametrize("fh,fw,t,lt", [(11, 12, 4, 3), (5, 18, 4, 3), (30, 54, 18, 11), (15, 27, 7, 5)])
+def test_window_attention_matches_oracle(backend, fh, fw, t, lt):
+    """Masked + unmasked windows, window padding, circular rolled neighbours and pooled tokens.  (30, 54, 18, 11) is the
+    BASELINE.json configs[1] geometry (640x360: 6x6 windows, 91 pooled keys, 18 frames, 810 queries per masked window:
+    several 128-query blocks with a ragged last one) -- MI355X only, the emulator would need minutes; (15, 27, 7, 5) has
+    315 queries per masked window: full and partial 128-query blocks under the emulator."""
     dev = backend
+    if backend.type == "cpu" and fh * fw * t > 5000:
+        pytest.skip("BASELINE-size case runs on the MI355X only")
     g = torch.Generator().manual_seed(34)
-    t, lt = 4, 3
     sd = weights.synth_state_dicts(1)["gen"]
     pre = "transformers.transformer.0.attention."
     x = torch.randn(1, t, fh, fw, 512, generator=g).half().float()  # "LayerNorm-ed" tokens
