@@ -111,20 +111,17 @@ __global__ void mask_coldil_kernel(const unsigned char* __restrict__ d, unsigned
 // Binary planes the generator derives from the dilated / updated masks (propainter.py:409-428):
 //   maskpair[t][i][j] = (m_in[t][4i][4j], m_upd[t][4i][4j], 0...) as 8 f16 channels (nearest x1/4),
 //   tokmask[t][a][b]  = MaxPool2d(7, 3, 3) of the 1/4-res m_in plane (> 0).
+template <typename T>
 __global__ void clip_masks_kernel(const unsigned char* __restrict__ m_in, const unsigned char* __restrict__ m_upd,
-                                  half_t* __restrict__ maskpair, int H, int W, int h, int w, int64_t total) {
+                                  T* __restrict__ maskpair, int H, int W, int h, int w, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int x = (int)(i % w);
   const int y = (int)((i / w) % h);
   const int64_t t = i / ((int64_t)w * h);
   const int64_t src = (t * H + 4 * y) * W + 4 * x;
-  h8 o;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) o[c] = (half_t)0.f;
-  o[0] = (half_t)(float)m_in[src];
-  o[1] = (half_t)(float)m_upd[src];
-  ((h8*)maskpair)[i] = o;
+  const float o[8] = {(float)m_in[src], (float)m_upd[src], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  st8(maskpair + i * 8, o);
 }
 
 __global__ void token_mask_kernel(const unsigned char* __restrict__ m_in, unsigned char* __restrict__ tok, int H, int W,
@@ -235,8 +232,15 @@ extern "C" int32_t pp_clip_masks(void* stream, const pp_clip_masks_params* p) {
   if (p->fh != fh || p->fw != fw) return pp_fail(PP_ERR_BAD_ARG, "pp_clip_masks: token grid does not match H, W");
   const int64_t total = p->T * h * w, ttok = p->T * fh * fw;
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_clip_masks: empty problem");
-  PP_LAUNCH(clip_masks_kernel, dim3(nblk(total)), dim3(256), 0, stream, (const unsigned char*)p->m_in,
-            (const unsigned char*)p->m_upd, (half_t*)p->maskpair, (int)p->H, (int)p->W, h, w, total);
+  if (p->dtype == PP_F16) {
+    PP_LAUNCH((clip_masks_kernel<half_t>), dim3(nblk(total)), dim3(256), 0, stream, (const unsigned char*)p->m_in,
+              (const unsigned char*)p->m_upd, (half_t*)p->maskpair, (int)p->H, (int)p->W, h, w, total);
+  } else if (p->dtype == PP_F32) {
+    PP_LAUNCH((clip_masks_kernel<float>), dim3(nblk(total)), dim3(256), 0, stream, (const unsigned char*)p->m_in,
+              (const unsigned char*)p->m_upd, (float*)p->maskpair, (int)p->H, (int)p->W, h, w, total);
+  } else {
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_clip_masks: dtype");
+  }
   PP_LAUNCH(token_mask_kernel, dim3(nblk(ttok)), dim3(256), 0, stream, (const unsigned char*)p->m_in,
             (unsigned char*)p->tokmask, (int)p->H, (int)p->W, h, w, fh, fw, ttok);
   return pp_check_launch("pp_clip_masks");

@@ -259,4 +259,39 @@ __device__ __forceinline__ float tanhf_(float x) {
 
 __device__ __forceinline__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// 8 consecutive elements of an f16 / f32 activation tensor as floats (one 16-byte / two 16-byte accesses): the storage
+// type of the two f16-capable networks is f16 for the node's fp16 "enable" and f32 for "disable".
+__device__ __forceinline__ void ld8(const half_t* p, float* f) {
+  const h8 v = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+__device__ __forceinline__ void ld8(const float* p, float* f) {
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[i] = a[i];
+    f[4 + i] = b[i];
+  }
+}
+__device__ __forceinline__ void st8(half_t* p, const float* f) {
+  h8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (half_t)f[i];
+  *reinterpret_cast<h8*>(p) = v;
+}
+__device__ __forceinline__ void st8(float* p, const float* f) {
+  *reinterpret_cast<f4*>(p) = f4{f[0], f[1], f[2], f[3]};
+  *reinterpret_cast<f4*>(p + 4) = f4{f[4], f[5], f[6], f[7]};
+}
+__device__ __forceinline__ h8 ld8h(const half_t* p) { return *reinterpret_cast<const h8*>(p); }
+__device__ __forceinline__ h8 ld8h(const float* p) {  // fp32 storage, f16 MFMA operand
+  float f[8];
+  ld8(p, f);
+  h8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (half_t)f[i];
+  return v;
+}
+
 }  // namespace pp

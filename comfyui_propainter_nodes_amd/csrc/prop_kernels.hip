@@ -123,11 +123,12 @@ __global__ void __launch_bounds__(256) img_prop_step_kernel(const float* __restr
   m_new[idx] = (mc && !fill) ? 1 : 0;
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) pack_encoder_input_kernel(const float* __restrict__ frames,
                                                                  const float* __restrict__ prop,
                                                                  const unsigned char* __restrict__ m_in,
                                                                  const unsigned char* __restrict__ m_upd,
-                                                                 half_t* __restrict__ out, float* __restrict__ updated,
+                                                                 T* __restrict__ out, float* __restrict__ updated,
                                                                  int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -138,9 +139,8 @@ __global__ void __launch_bounds__(256) pack_encoder_input_kernel(const float* __
     v[c] = frames[idx * 3 + c] * (1.f - m) + prop[idx * 3 + c] * m;
     if (updated) updated[idx * 3 + c] = v[c];
   }
-  h8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)m, (half_t)(m_upd[idx] ? 1.f : 0.f),
-          (half_t)0.f, (half_t)0.f, (half_t)0.f};
-  *reinterpret_cast<h8*>(out + idx * 8) = o;
+  const float o[8] = {v[0], v[1], v[2], m, m_upd[idx] ? 1.f : 0.f, 0.f, 0.f, 0.f};
+  st8(out + idx * 8, o);
 }
 
 __global__ void __launch_bounds__(256) flow_down4_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
@@ -162,9 +162,10 @@ __global__ void __launch_bounds__(256) flow_down4_kernel(const float* __restrict
   }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) featprop_aux_kernel(const float* __restrict__ flow_prop,
                                                            const float* __restrict__ flow_check,
-                                                           const half_t* __restrict__ maskpair, half_t* __restrict__ out,
+                                                           const T* __restrict__ maskpair, T* __restrict__ out,
                                                            int H, int W, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over N*H*W
   if (idx >= total) return;
@@ -175,9 +176,9 @@ __global__ void __launch_bounds__(256) featprop_aux_kernel(const float* __restri
   const float fx = flow_prop[idx * 2], fy = flow_prop[idx * 2 + 1];
   const float ix = warp_coord(x, fx, W), iy = warp_coord(y, fy, H);
   const bool valid = fb_valid(flow_check + n * (int64_t)hw * 2, H, W, fx, fy, ix, iy);
-  const half_t* mp = maskpair + idx * 8;
-  h8 o = {(half_t)fx, (half_t)fy, (half_t)(valid ? 1.f : 0.f), mp[0], mp[1], (half_t)0.f, (half_t)0.f, (half_t)0.f};
-  *reinterpret_cast<h8*>(out + idx * 8) = o;
+  const T* mp = maskpair + idx * 8;
+  const float o[8] = {fx, fy, valid ? 1.f : 0.f, (float)mp[0], (float)mp[1], 0.f, 0.f, 0.f};
+  st8(out + idx * 8, o);
 }
 
 template <typename T>
@@ -239,9 +240,17 @@ extern "C" int32_t pp_pack_encoder_input(void* stream, const pp_pack_encoder_inp
   if (!p || !p->frames || !p->prop || !p->m_in || !p->m_upd || !p->out)
     return pp_fail(PP_ERR_BAD_ARG, "pp_pack_encoder_input: null argument");
   if (p->total_pixels <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_pack_encoder_input: empty problem");
-  PP_LAUNCH(pack_encoder_input_kernel, dim3(nblk2(p->total_pixels)), dim3(256), 0, stream, (const float*)p->frames,
-            (const float*)p->prop, (const unsigned char*)p->m_in, (const unsigned char*)p->m_upd, (half_t*)p->out,
-            (float*)p->updated, p->total_pixels);
+  if (p->out_dtype == PP_F16) {
+    PP_LAUNCH((pack_encoder_input_kernel<half_t>), dim3(nblk2(p->total_pixels)), dim3(256), 0, stream, (const float*)p->frames,
+              (const float*)p->prop, (const unsigned char*)p->m_in, (const unsigned char*)p->m_upd, (half_t*)p->out,
+              (float*)p->updated, p->total_pixels);
+  } else if (p->out_dtype == PP_F32) {
+    PP_LAUNCH((pack_encoder_input_kernel<float>), dim3(nblk2(p->total_pixels)), dim3(256), 0, stream, (const float*)p->frames,
+              (const float*)p->prop, (const unsigned char*)p->m_in, (const unsigned char*)p->m_upd, (float*)p->out,
+              (float*)p->updated, p->total_pixels);
+  } else {
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_pack_encoder_input: out_dtype");
+  }
   return pp_check_launch("pp_pack_encoder_input");
 }
 
@@ -263,8 +272,15 @@ extern "C" int32_t pp_featprop_aux(void* stream, const pp_featprop_aux_params* p
     return pp_fail(PP_ERR_BAD_ARG, "pp_featprop_aux: null argument");
   const int64_t total = p->N * p->H * p->W;
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_featprop_aux: empty problem");
-  PP_LAUNCH(featprop_aux_kernel, dim3(nblk2(total)), dim3(256), 0, stream, (const float*)p->flow_prop,
-            (const float*)p->flow_check, (const half_t*)p->maskpair, (half_t*)p->out, (int)p->H, (int)p->W, total);
+  if (p->dtype == PP_F16) {
+    PP_LAUNCH((featprop_aux_kernel<half_t>), dim3(nblk2(total)), dim3(256), 0, stream, (const float*)p->flow_prop,
+              (const float*)p->flow_check, (const half_t*)p->maskpair, (half_t*)p->out, (int)p->H, (int)p->W, total);
+  } else if (p->dtype == PP_F32) {
+    PP_LAUNCH((featprop_aux_kernel<float>), dim3(nblk2(total)), dim3(256), 0, stream, (const float*)p->flow_prop,
+              (const float*)p->flow_check, (const float*)p->maskpair, (float*)p->out, (int)p->H, (int)p->W, total);
+  } else {
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_featprop_aux: dtype");
+  }
   return pp_check_launch("pp_featprop_aux");
 }
 

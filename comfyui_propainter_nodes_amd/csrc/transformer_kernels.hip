@@ -12,21 +12,19 @@ static inline unsigned nblk3(int64_t total) { return (unsigned)((total + 255) / 
 // ----------------------------------------------------------------------------------------
 // LayerNorm: one wave per token, 8 channels per lane (C = 512)
 // ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) layernorm512_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm512_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int fh, int fw, int Hp,
                                                            int Wp, int64_t ntok, float eps) {
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = lane_id();
   const int64_t tk = tok < ntok ? tok : ntok - 1;  // keep the wave convergent for the shuffles
-  const h8 v = *reinterpret_cast<const h8*>(x + tk * 512 + lane * 8);
   float f[8];
+  ld8(x + tk * 512 + lane * 8, f);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    f[i] = (float)v[i];
-    s += f[i];
-  }
+  for (int i = 0; i < 8; ++i) s += f[i];
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) s += shfl_xor(s, m);
   const float mean = s * (1.f / 512.f);
@@ -44,17 +42,18 @@ __global__ void __launch_bounds__(256) layernorm512_kernel(const half_t* __restr
   const int64_t t = tok / per;
   const int r = (int)(tok % per);
   const int y = r / fw, xx = r - y * fw;
-  half_t* dst = out + ((t * Hp + y) * (int64_t)Wp + xx) * 512 + lane * 8;
-  h8 o;
+  T* dst = out + ((t * Hp + y) * (int64_t)Wp + xx) * 512 + lane * 8;
+  float o[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = (half_t)(f[i] * rstd * gamma[lane * 8 + i] + beta[lane * 8 + i]);
-  *reinterpret_cast<h8*>(dst) = o;
+  for (int i = 0; i < 8; ++i) o[i] = f[i] * rstd * gamma[lane * 8 + i] + beta[lane * 8 + i];
+  st8(dst, o);
 }
 
 // ----------------------------------------------------------------------------------------
 // depth-wise 4x4 stride-4 token pooling
 // ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) pool_tokens_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
+template <typename T>
+__global__ void __launch_bounds__(256) pool_tokens_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                           const float* __restrict__ w, const float* __restrict__ b,
                                                           int Hp, int Wp, int C, int ph, int pw, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over T*ph*pw*(C/8)
@@ -71,15 +70,13 @@ __global__ void __launch_bounds__(256) pool_tokens_kernel(const half_t* __restri
   for (int c = 0; c < 8; ++c) acc[c] = b[pc * 8 + c];
   for (int ky = 0; ky < 4; ++ky)
     for (int kx = 0; kx < 4; ++kx) {
-      const h8 v = *reinterpret_cast<const h8*>(x + ((t * Hp + 4 * i + ky) * (int64_t)Wp + 4 * j + kx) * C + pc * 8);
+      float v[8];
+      ld8(x + ((t * Hp + 4 * i + ky) * (int64_t)Wp + 4 * j + kx) * C + pc * 8, v);
       const float* ww = w + (ky * 4 + kx) * C + pc * 8;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] += (float)v[c] * ww[c];
+      for (int c = 0; c < 8; ++c) acc[c] += v[c] * ww[c];
     }
-  h8 o;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[c];
-  *reinterpret_cast<h8*>(out + tok * C + pc * 8) = o;
+  st8(out + tok * C + pc * 8, acc);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -99,12 +96,13 @@ __global__ void __launch_bounds__(256) pool_tokens_kernel(const half_t* __restri
 // stores per thread and tile (r01).  The fragment reads use one row block (dt) per instruction, so the XOR is uniform
 // across a read's lanes and they stay conflict-free.
 // ----------------------------------------------------------------------------------------
+template <typename T>
 struct AttnK {
-  const half_t* qkv;
-  const half_t* pkv;
+  const T* qkv;
+  const T* pkv;
   const int* win_masked;
   const int* t_ind;
-  half_t* out;
+  T* out;
   int t, nt, Hp, Wp, fh, fw, npool, nww;
   float scale;
   signed char nb[148 * 2];
@@ -116,7 +114,8 @@ constexpr int kVP = 32 + 8;        // V^T tile row pitch (halves)
 constexpr int kQG = 2;             // 16-query groups per wave
 constexpr int kQBlock = 4 * kQG * 16;
 
-__global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
+template <typename T>
+__global__ void __launch_bounds__(256) window_attention_kernel(const AttnK<T> k) {
   __shared__ __attribute__((aligned(16))) half_t Ks[32 * kKP];
   __shared__ __attribute__((aligned(16))) half_t Vt[kHeadDim * kVP];
 
@@ -155,9 +154,9 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
     const int qpos = masked ? qc - qt[qi] * kWinTok : qc;
     qy[qi] = r0 + qpos / kWinW;
     qx[qi] = c0 + qpos % kWinW;
-    const half_t* qptr = k.qkv + ((int64_t)(qt[qi] * k.Hp + qy[qi]) * k.Wp + qx[qi]) * (3 * kDim) + head * kHeadDim;
+    const T* qptr = k.qkv + ((int64_t)(qt[qi] * k.Hp + qy[qi]) * k.Wp + qx[qi]) * (3 * kDim) + head * kHeadDim;
 #pragma unroll
-    for (int dc = 0; dc < 4; ++dc) qf[qi][dc] = *reinterpret_cast<const h8*>(qptr + dc * 32 + g * 8);
+    for (int dc = 0; dc < 4; ++dc) qf[qi][dc] = ld8h(qptr + dc * 32 + g * 8);  // (fp32 storage: f16 MFMA operands)
   }
 
   f4 o[kQG][8];
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) kv0[e] = kv1[e] = vv0[e] = vv1[e] = (half_t)0.f;
       if (kid < nk) {
-        const half_t *kp, *vp;
+        const T *kp, *vp;
         int fr, r;
         if (masked) {
           const int fi = kid / per_frame;
@@ -204,18 +203,18 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
             y = (r0 + (int)k.nb[2 * ni] + k.Hp) % k.Hp;
             x = (c0 + (int)k.nb[2 * ni + 1] + k.Wp) % k.Wp;
           }
-          const half_t* tokp = k.qkv + ((int64_t)(fr * k.Hp + y) * k.Wp + x) * (3 * kDim) + head * kHeadDim;
+          const T* tokp = k.qkv + ((int64_t)(fr * k.Hp + y) * k.Wp + x) * (3 * kDim) + head * kHeadDim;
           kp = tokp + kDim;
           vp = tokp + 2 * kDim;
         } else {
-          const half_t* tokp = k.pkv + ((int64_t)fr * k.npool + (r - kWinTok - 148)) * (2 * kDim) + head * kHeadDim;
+          const T* tokp = k.pkv + ((int64_t)fr * k.npool + (r - kWinTok - 148)) * (2 * kDim) + head * kHeadDim;
           kp = tokp;
           vp = tokp + kDim;
         }
-        kv0 = *reinterpret_cast<const h8*>(kp + dbase);
-        kv1 = *reinterpret_cast<const h8*>(kp + dbase + 8);
-        vv0 = *reinterpret_cast<const h8*>(vp + dbase);
-        vv1 = *reinterpret_cast<const h8*>(vp + dbase + 8);
+        kv0 = ld8h(kp + dbase);
+        kv1 = ld8h(kp + dbase + 8);
+        vv0 = ld8h(vp + dbase);
+        vv1 = ld8h(vp + dbase + 8);
       }
       *reinterpret_cast<h8*>(Ks + kr * kKP + dbase) = kv0;
       *reinterpret_cast<h8*>(Ks + kr * kKP + dbase + 8) = kv1;
@@ -292,12 +291,16 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
   for (int qi = 0; qi < kQG; ++qi) {
     if (!qvalid[qi] || qy[qi] >= k.fh || qx[qi] >= k.fw) continue;
     const float inv = 1.f / l_run[qi];
-    half_t* dst = k.out + ((int64_t)(qt[qi] * k.fh + qy[qi]) * k.fw + qx[qi]) * kDim + head * kHeadDim;
+    T* dst = k.out + ((int64_t)(qt[qi] * k.fh + qy[qi]) * k.fw + qx[qi]) * kDim + head * kHeadDim;
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
-      h4 v = {(half_t)(o[qi][dt][0] * inv), (half_t)(o[qi][dt][1] * inv), (half_t)(o[qi][dt][2] * inv),
-              (half_t)(o[qi][dt][3] * inv)};
-      *reinterpret_cast<h4*>(dst + dt * 16 + 4 * g) = v;
+      if constexpr (sizeof(T) == 2) {
+        h4 v = {(half_t)(o[qi][dt][0] * inv), (half_t)(o[qi][dt][1] * inv), (half_t)(o[qi][dt][2] * inv),
+                (half_t)(o[qi][dt][3] * inv)};
+        *reinterpret_cast<h4*>(dst + dt * 16 + 4 * g) = v;
+      } else {
+        *reinterpret_cast<f4*>(dst + dt * 16 + 4 * g) = o[qi][dt] * inv;
+      }
     }
   }
 }
@@ -305,7 +308,8 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK k) {
 // ----------------------------------------------------------------------------------------
 // fold (overlap-add [+average]) and unfold+GELU, kernel 7 / stride 3 / padding 3, tap-major vectors
 // ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fold_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int H,
+template <typename T>
+__global__ void __launch_bounds__(256) fold_kernel(const T* __restrict__ in, T* __restrict__ out, int H,
                                                    int W, int C, int fh, int fw, int normalize, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over T*H*W*(C/8)
   if (idx >= total) return;
@@ -328,20 +332,21 @@ __global__ void __launch_bounds__(256) fold_kernel(const half_t* __restrict__ in
     const int ky = y - (3 * i - 3);
     for (int j = j0; j <= j1; ++j) {
       const int kx = x - (3 * j - 3);
-      const half_t* src = in + ((t * fh + i) * (int64_t)fw + j) * (49 * C) + (ky * 7 + kx) * C + pc * 8;
-      const h8 v = *reinterpret_cast<const h8*>(src);
+      float v[8];
+      ld8(in + ((t * fh + i) * (int64_t)fw + j) * (49 * C) + (ky * 7 + kx) * C + pc * 8, v);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] += (float)v[c];
+      for (int c = 0; c < 8; ++c) acc[c] += v[c];
     }
   }
   const int cnt = (i1 - i0 + 1) * (j1 - j0 + 1);
-  h8 o;
+  float o[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) o[c] = (half_t)((normalize && cnt > 0) ? acc[c] / (float)cnt : acc[c]);
-  *reinterpret_cast<h8*>(out + pix * C + pc * 8) = o;
+  for (int c = 0; c < 8; ++c) o[c] = (normalize && cnt > 0) ? acc[c] / (float)cnt : acc[c];
+  st8(out + pix * C + pc * 8, o);
 }
 
-__global__ void __launch_bounds__(256) unfold_gelu_kernel(const half_t* __restrict__ in, half_t* __restrict__ out,
+template <typename T>
+__global__ void __launch_bounds__(256) unfold_gelu_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                           int H, int W, int C, int fh, int fw, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over T*fh*fw*49*(C/8)
   if (idx >= total) return;
@@ -355,24 +360,23 @@ __global__ void __launch_bounds__(256) unfold_gelu_kernel(const half_t* __restri
   const int i = (int)(r % fh);
   const int64_t t = r / fh;
   const int y = 3 * i - 3 + tap / 7, x = 3 * j - 3 + tap % 7;
-  h8 o;
+  float o[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) o[c] = (half_t)0.f;
+  for (int c = 0; c < 8; ++c) o[c] = 0.f;
   if (y >= 0 && y < H && x >= 0 && x < W) {
-    const h8 v = *reinterpret_cast<const h8*>(in + ((t * H + y) * (int64_t)W + x) * C + pc * 8);
+    float v[8];
+    ld8(in + ((t * H + y) * (int64_t)W + x) * C + pc * 8, v);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float f = (float)v[c];
-      o[c] = (half_t)(0.5f * f * (1.f + erff(f * 0.70710678118654752f)));
-    }
+    for (int c = 0; c < 8; ++c) o[c] = 0.5f * v[c] * (1.f + erff(v[c] * 0.70710678118654752f));
   }
-  *reinterpret_cast<h8*>(out + ((t * fh + i) * (int64_t)fw + j) * (49 * C) + tap * C + pc * 8) = o;
+  st8(out + ((t * fh + i) * (int64_t)fw + j) * (49 * C) + tap * C + pc * 8, o);
 }
 
 // ----------------------------------------------------------------------------------------
 // uint8 compose
 // ----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) compose_u8_kernel(const half_t* __restrict__ pred, int pred_ldc,
+template <typename T>
+__global__ void __launch_bounds__(256) compose_u8_kernel(const T* __restrict__ pred, int pred_ldc,
                                                          const int* __restrict__ frame_ids,
                                                          const int* __restrict__ first,
                                                          const unsigned char* __restrict__ masks,
@@ -411,9 +415,19 @@ extern "C" int32_t pp_layernorm(void* stream, const pp_layernorm_params* p) {
   if (p->C != 512) return pp_fail(PP_ERR_UNSUPPORTED, "pp_layernorm: C must be 512");
   const int64_t ntok = p->T * p->fh * p->fw;
   if (ntok <= 0 || p->Hp < p->fh || p->Wp < p->fw) return pp_fail(PP_ERR_BAD_ARG, "pp_layernorm: bad geometry");
-  PP_LAUNCH(layernorm512_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, stream, (const half_t*)p->x,
-            (half_t*)p->out, (const float*)p->gamma, (const float*)p->beta, (int)p->fh, (int)p->fw, (int)p->Hp,
-            (int)p->Wp, ntok, p->eps);
+#define PP_BY_DTYPE(DT, CALL)                                               \
+  if ((DT) == PP_F16) {                                                     \
+    typedef half_t T;                                                       \
+    CALL;                                                                   \
+  } else if ((DT) == PP_F32) {                                              \
+    typedef float T;                                                        \
+    CALL;                                                                   \
+  } else {                                                                  \
+    return pp_fail(PP_ERR_UNSUPPORTED, "storage dtype must be PP_F16 or PP_F32"); \
+  }
+  PP_BY_DTYPE(p->dtype, PP_LAUNCH((layernorm512_kernel<T>), dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, stream,
+                                  (const T*)p->x, (T*)p->out, (const float*)p->gamma, (const float*)p->beta, (int)p->fh,
+                                  (int)p->fw, (int)p->Hp, (int)p->Wp, ntok, p->eps))
   return pp_check_launch("pp_layernorm");
 }
 
@@ -424,23 +438,21 @@ extern "C" int32_t pp_pool_tokens(void* stream, const pp_pool_tokens_params* p) 
   const int ph = (int)(p->Hp / 4), pw = (int)(p->Wp / 4);
   const int64_t total = p->T * ph * pw * (p->C / 8);
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_pool_tokens: empty problem");
-  PP_LAUNCH(pool_tokens_kernel, dim3(nblk3(total)), dim3(256), 0, stream, (const half_t*)p->x, (half_t*)p->out,
-            (const float*)p->weight, (const float*)p->bias, (int)p->Hp, (int)p->Wp, (int)p->C, ph, pw, total);
+  PP_BY_DTYPE(p->dtype, PP_LAUNCH((pool_tokens_kernel<T>), dim3(nblk3(total)), dim3(256), 0, stream, (const T*)p->x,
+                                  (T*)p->out, (const float*)p->weight, (const float*)p->bias, (int)p->Hp, (int)p->Wp,
+                                  (int)p->C, ph, pw, total))
   return pp_check_launch("pp_pool_tokens");
 }
 
-extern "C" int32_t pp_window_attention(void* stream, const pp_window_attention_params* p) {
+template <typename T>
+static int launch_window_attention(void* stream, const pp_window_attention_params* p) {
   using namespace pp;
-  if (!p || !p->qkv || !p->pkv || !p->win_masked || !p->t_ind || !p->out)
-    return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: null argument");
-  if (p->Hp % kWinH || p->Wp % kWinW) return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: grid not padded to 5x9 windows");
-  if (p->t < 1 || p->nt < 1 || p->t > 65535) return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: bad t / nt");
-  AttnK k;
-  k.qkv = (const half_t*)p->qkv;
-  k.pkv = (const half_t*)p->pkv;
+  AttnK<T> k;
+  k.qkv = (const T*)p->qkv;
+  k.pkv = (const T*)p->pkv;
   k.win_masked = (const int*)p->win_masked;
   k.t_ind = (const int*)p->t_ind;
-  k.out = (half_t*)p->out;
+  k.out = (T*)p->out;
   k.t = (int)p->t; k.nt = (int)p->nt; k.Hp = (int)p->Hp; k.Wp = (int)p->Wp; k.fh = (int)p->fh; k.fw = (int)p->fw;
   k.npool = (int)p->npool;
   k.nww = k.Wp / kWinW;
@@ -462,8 +474,19 @@ extern "C" int32_t pp_window_attention(void* stream, const pp_window_attention_p
   if (n != 148) return pp_fail(PP_ERR_LAUNCH, "pp_window_attention: internal neighbour table error");
   const int nwin = (k.Hp / kWinH) * k.nww;
   dim3 grid((unsigned)k.t, kHeads, (unsigned)nwin);
-  PP_LAUNCH(window_attention_kernel, grid, dim3(256), 0, stream, k);
+  PP_LAUNCH((window_attention_kernel<T>), grid, dim3(256), 0, stream, k);
   return pp_check_launch("pp_window_attention");
+}
+
+extern "C" int32_t pp_window_attention(void* stream, const pp_window_attention_params* p) {
+  using namespace pp;
+  if (!p || !p->qkv || !p->pkv || !p->win_masked || !p->t_ind || !p->out)
+    return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: null argument");
+  if (p->Hp % kWinH || p->Wp % kWinW) return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: grid not padded to 5x9 windows");
+  if (p->t < 1 || p->nt < 1 || p->t > 65535) return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: bad t / nt");
+  if (p->dtype == PP_F16) return launch_window_attention<half_t>(stream, p);
+  if (p->dtype == PP_F32) return launch_window_attention<float>(stream, p);
+  return pp_fail(PP_ERR_UNSUPPORTED, "pp_window_attention: dtype");
 }
 
 extern "C" int32_t pp_fold(void* stream, const pp_fold_params* p) {
@@ -472,8 +495,8 @@ extern "C" int32_t pp_fold(void* stream, const pp_fold_params* p) {
   if (p->C % 8) return pp_fail(PP_ERR_BAD_ARG, "pp_fold: C must be a multiple of 8");
   const int64_t total = p->T * p->H * p->W * (p->C / 8);
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_fold: empty problem");
-  PP_LAUNCH(fold_kernel, dim3(nblk3(total)), dim3(256), 0, stream, (const half_t*)p->in, (half_t*)p->out, (int)p->H,
-            (int)p->W, (int)p->C, (int)p->fh, (int)p->fw, (int)p->normalize, total);
+  PP_BY_DTYPE(p->dtype, PP_LAUNCH((fold_kernel<T>), dim3(nblk3(total)), dim3(256), 0, stream, (const T*)p->in, (T*)p->out,
+                                  (int)p->H, (int)p->W, (int)p->C, (int)p->fh, (int)p->fw, (int)p->normalize, total))
   return pp_check_launch("pp_fold");
 }
 
@@ -483,8 +506,8 @@ extern "C" int32_t pp_unfold_gelu(void* stream, const pp_unfold_gelu_params* p) 
   if (p->C % 8) return pp_fail(PP_ERR_BAD_ARG, "pp_unfold_gelu: C must be a multiple of 8");
   const int64_t total = p->T * p->fh * p->fw * 49 * (p->C / 8);
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_unfold_gelu: empty problem");
-  PP_LAUNCH(unfold_gelu_kernel, dim3(nblk3(total)), dim3(256), 0, stream, (const half_t*)p->in, (half_t*)p->out,
-            (int)p->H, (int)p->W, (int)p->C, (int)p->fh, (int)p->fw, total);
+  PP_BY_DTYPE(p->dtype, PP_LAUNCH((unfold_gelu_kernel<T>), dim3(nblk3(total)), dim3(256), 0, stream, (const T*)p->in,
+                                  (T*)p->out, (int)p->H, (int)p->W, (int)p->C, (int)p->fh, (int)p->fw, total))
   return pp_check_launch("pp_unfold_gelu");
 }
 
@@ -495,8 +518,9 @@ extern "C" int32_t pp_compose_u8(void* stream, const pp_compose_u8_params* p) {
   const int64_t HW = p->H * p->W;
   const int64_t total = p->L * HW;
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_compose_u8: empty problem");
-  PP_LAUNCH(compose_u8_kernel, dim3(nblk3(total)), dim3(256), 0, stream, (const half_t*)p->pred, (int)p->pred_ldc,
-            (const int*)p->frame_ids, (const int*)p->first, (const unsigned char*)p->masks,
-            (const unsigned char*)p->orig, (unsigned char*)p->comp, HW, total);
+  PP_BY_DTYPE(p->pred_dtype, PP_LAUNCH((compose_u8_kernel<T>), dim3(nblk3(total)), dim3(256), 0, stream, (const T*)p->pred,
+                                       (int)p->pred_ldc, (const int*)p->frame_ids, (const int*)p->first,
+                                       (const unsigned char*)p->masks, (const unsigned char*)p->orig,
+                                       (unsigned char*)p->comp, HW, total))
   return pp_check_launch("pp_compose_u8");
 }

@@ -108,6 +108,7 @@ class GpuBackend:
 
     def __init__(self, models: Models, config: ProPainterConfig):
         self.m, self.cfg = models, config
+        self.act_dtype = models.inpaint_model.dt   # storage type of encoder features / window outputs on the wire
 
     def raft(self, frames):                     # fp32 [n,H,W,3] -> [2,n-1,H,W,2]
         ff, fb = self.m.raft_model(frames, self.cfg.raft_iter)
@@ -121,7 +122,7 @@ class GpuBackend:
 
     def encode(self, frames, prop, md, upd):
         n, H, W, _ = frames.shape
-        packed = torch.empty(n, H, W, 8, device=frames.device, dtype=torch.float16)
+        packed = torch.empty(n, H, W, 8, device=frames.device, dtype=self.m.inpaint_model.dt)
         ops.pack_encoder_input(frames.contiguous(), prop.contiguous(), md.contiguous(), upd.contiguous(), packed)
         return self.m.inpaint_model.encode(packed)
 
@@ -262,7 +263,7 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
     enc_shape = yield torch.tensor(list(enc_own.shape[1:]) if enc_own is not None else [0, 0, 0], device=dev)
     eshape = [int(v) for v in max(enc_shape, key=lambda t: int(t.sum()))]
     if enc_own is None:
-        enc_own = torch.zeros([0] + eshape, device=dev, dtype=torch.float16)
+        enc_own = torch.zeros([0] + eshape, device=dev, dtype=getattr(backend, "act_dtype", torch.float16))
     # x2: encoder features + updated masks of the frames this rank's windows read (+-45 frames at the defaults)
     enc_s = yield from _halo_exchange(enc_own, plan.frame_ranges, plan.rank, need2)
     upd_s = yield from _halo_exchange(upd, plan.frame_ranges, plan.rank, need2)
@@ -293,7 +294,7 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
     pred_tail = tuple(int(v) for v in max(tail_g, key=lambda t: int(t.sum())))
     sends = {dst: torch.stack([preds[wi][schedule[wi][0].index(idx)] for wi, idx in lst], 0)
              for dst, lst in exports[plan.rank].items()}
-    recvs = {src: ((len(exports[src][plan.rank]),) + pred_tail, torch.float16)
+    recvs = {src: ((len(exports[src][plan.rank]),) + pred_tail, getattr(backend, "act_dtype", torch.float16))
              for src in range(plan.world) if src != plan.rank and plan.rank in exports[src]}
     got = yield ("p2p", sends, recvs)
     foreign = {}

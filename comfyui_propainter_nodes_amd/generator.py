@@ -41,23 +41,29 @@ class ClipState:
 
 
 class InpaintGeneratorMI355:
-    def __init__(self, sd: dict, device):
+    def __init__(self, sd: dict, device, dtype: torch.dtype = F16):
+        """`dtype` = storage type of the activations: f16 (the node's fp16 "enable": the reference runs the generator
+        `.half()`) or f32 (fp16 "disable").  In f32 the convolutions / linears multiply with the two-term operand split of
+        PP_F32X2 (or on the f32 MFMA instructions under PP_F32_GEMM=exact); the attention core rounds q, k, v and the
+        probabilities to f16 for its MFMAs and keeps scores, statistics, accumulators and outputs in fp32."""
         self.device = torch.device(device)
+        self.dt = dtype
+        self.split = dtype == torch.float32 and ops.f32_split_enabled()
         self._graphs = graphs.GraphCache()
         p = {k: v.float() for k, v in sd.items() if v.is_floating_point()}
         dev = device
 
         def conv(name, **kw):
-            return ops.make_conv_spec(p[name + ".weight"], p[name + ".bias"], F16, **kw).to(dev)
+            return ops.make_conv_spec(p[name + ".weight"], p[name + ".bias"], self.dt, split=self.split, **kw).to(dev)
 
         def linear(w, b, **kw):
-            return ops.make_conv_spec(w.reshape(w.shape[0], w.shape[1], 1, 1), b, F16, **kw).to(dev)
+            return ops.make_conv_spec(w.reshape(w.shape[0], w.shape[1], 1, 1), b, self.dt, split=self.split, **kw).to(dev)
 
         # ---- encoder (propainter.py:234-275) ----------------------------------------------------
         w0 = p["encoder.layers.0.weight"]  # [64,5,3,3] -> im2col over the 5 packed channels
         self.enc0_kpad = ops.pad32(45)
-        self.enc0 = ops.make_conv_spec(w0.permute(0, 2, 3, 1).reshape(64, 45, 1, 1), p["encoder.layers.0.bias"], F16,
-                                       seg_channels=[self.enc0_kpad], seg_valid=[45]).to(dev)
+        self.enc0 = ops.make_conv_spec(w0.permute(0, 2, 3, 1).reshape(64, 45, 1, 1), p["encoder.layers.0.bias"], self.dt,
+                                       seg_channels=[self.enc0_kpad], seg_valid=[45], split=self.split).to(dev)
         self.enc2 = conv("encoder.layers.2", padding=1)
         self.enc4 = conv("encoder.layers.4", stride=2, padding=1)
         self.enc6 = conv("encoder.layers.6", padding=1)
@@ -78,15 +84,15 @@ class InpaintGeneratorMI355:
                 "off4": conv(da + "conv_offset.4", padding=1),
                 "off6": conv(da + "conv_offset.6", padding=1),
                 "dcn": ops.make_conv_spec(p[da + "weight"].permute(0, 2, 3, 1).reshape(128, 9 * 128, 1, 1), p[da + "bias"],
-                                          F16).to(dev),
+                                          self.dt, split=self.split).to(dev),
                 "bb0": conv(f"{fp}backbone.{name}.0", padding=1, seg_channels=[128, 128, 8], seg_valid=[128, 128, 2]),
                 "bb2": conv(f"{fp}backbone.{name}.2", padding=1),
             }
         self.fuse0 = conv(fp + "fuse.0", padding=1, seg_channels=[128, 128, 8], seg_valid=[128, 128, 2])
         self.fuse2 = conv(fp + "fuse.2", padding=1)
         # ---- soft split / composition (sparse_transformer.py:8-64) --------------------------------
-        self.ss = ops.make_conv_spec(p["ss.embedding.weight"].view(512, 128, 7, 7), p["ss.embedding.bias"], F16, stride=3,
-                                     padding=3).to(dev)
+        self.ss = ops.make_conv_spec(p["ss.embedding.weight"].view(512, 128, 7, 7), p["ss.embedding.bias"], self.dt, stride=3,
+                                     padding=3, split=self.split).to(dev)
         wsc = p["sc.embedding.weight"].view(128, 49, 512).permute(1, 0, 2).reshape(6272, 512)  # rows -> tap-major
         bsc = p["sc.embedding.bias"].view(128, 49).t().reshape(6272)
         self.sc = linear(wsc, bsc)
@@ -125,13 +131,13 @@ class InpaintGeneratorMI355:
         T, H, W, _ = packed.shape
         h2, w2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         h4, w4 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1
-        out = torch.empty(T, h4, w4, 128, device=dev, dtype=F16)
+        out = torch.empty(T, h4, w4, 128, device=dev, dtype=self.dt)
         for s in range(0, T, chunk):
             e = min(T, s + chunk)
             n = e - s
 
             def new(hh, ww, c):
-                return torch.empty(n, hh, ww, c, device=dev, dtype=F16)
+                return torch.empty(n, hh, ww, c, device=dev, dtype=self.dt)
 
             cols = ops.im2col(packed[s:e][..., 0:5], new(h2, w2, self.enc0_kpad), 3, 3, stride=2, padding=1)
             a = ops.conv2d(self.enc0, [cols], new(h2, w2, 64), act="leaky", act_param=0.2)
@@ -160,9 +166,10 @@ class InpaintGeneratorMI355:
         ops.flow_down4(flows.view(2 * (T - 1), H, W, 2), ds)
         st.flow_f, st.flow_b = ds[:T - 1], ds[T - 1:]
         # nearest x1/4 mask planes + MaxPool2d(7,3,3) token masks (propainter.py:409-428): binary plumbing on the device
-        st.maskpair, st.tokmask = ops.clip_masks(masks_in_u8.contiguous(), masks_upd_u8.contiguous(), *token_grid(h, w))
-        st.aux_b = torch.empty(T - 1, h, w, 8, device=dev, dtype=F16)
-        st.aux_f = torch.empty(T - 1, h, w, 8, device=dev, dtype=F16)
+        st.maskpair, st.tokmask = ops.clip_masks(masks_in_u8.contiguous(), masks_upd_u8.contiguous(), *token_grid(h, w),
+                                                 dtype=self.dt)
+        st.aux_b = torch.empty(T - 1, h, w, 8, device=dev, dtype=self.dt)
+        st.aux_f = torch.empty(T - 1, h, w, 8, device=dev, dtype=self.dt)
         ops.featprop_aux(st.flow_f, st.flow_b, st.maskpair[:T - 1], st.aux_b)
         ops.featprop_aux(st.flow_b, st.flow_f, st.maskpair[1:], st.aux_f)
         return st
@@ -199,8 +206,8 @@ class InpaintGeneratorMI355:
         def gather(t: torch.Tensor, idx: int) -> torch.Tensor:
             return t.index_select(0, ops.device_ints([g + idx for g in g0s], dev))  # [nw, ...] rows (plain copy)
 
-        def buf(c, dt=F16):
-            return torch.empty(nw, h, w, c, device=dev, dtype=dt)
+        def buf(c, dt=None):
+            return torch.empty(nw, h, w, c, device=dev, dtype=dt or self.dt)
 
         x = torch.stack([gather(enc, i) for i in range(lt)], 0)            # [lt,nw,h,w,128]
         mp = torch.stack([gather(maskpair, i) for i in range(lt)], 0)      # [lt,nw,h,w,8]
@@ -211,7 +218,7 @@ class InpaintGeneratorMI355:
         src = x
         for name in ("backward_1", "forward_1"):
             S = self.prop[name]
-            out = torch.empty(lt, nw, h, w, 128, device=dev, dtype=F16)
+            out = torch.empty(lt, nw, h, w, 128, device=dev, dtype=self.dt)
             order = list(range(lt - 1, -1, -1)) if name == "backward_1" else list(range(lt))
             prop = None
             for i, idx in enumerate(order):
@@ -237,8 +244,8 @@ class InpaintGeneratorMI355:
             outs[name] = out
             src = out
         n = lt * nw
-        tmp = torch.empty(n, h, w, 128, device=dev, dtype=F16)
-        res = torch.empty(lt, nw, h, w, 128, device=dev, dtype=F16)
+        tmp = torch.empty(n, h, w, 128, device=dev, dtype=self.dt)
+        res = torch.empty(lt, nw, h, w, 128, device=dev, dtype=self.dt)
         ops.conv2d(self.fuse0, [outs["backward_1"].view(n, h, w, 128), outs["forward_1"].view(n, h, w, 128), mp.view(n, h, w, 8)],
                    tmp, act="leaky", act_param=0.2)
         ops.conv2d(self.fuse2, [tmp], res.view(n, h, w, 128), epi="add", aux1=x.view(n, h, w, 128))
@@ -250,15 +257,15 @@ class InpaintGeneratorMI355:
         h, w = hw
         Hp, Wp = math.ceil(fh / WIN[0]) * WIN[0], math.ceil(fw / WIN[1]) * WIN[1]
         ph, pw = Hp // 4, Wp // 4
-        xn = torch.zeros(t, Hp, Wp, 512, device=dev, dtype=F16)  # pad tokens stay zero (:212-216)
-        qkv = torch.empty(t, Hp, Wp, 1536, device=dev, dtype=F16)
-        pooled = torch.empty(t, ph, pw, 512, device=dev, dtype=F16)
-        pkv = torch.empty(t, ph, pw, 1024, device=dev, dtype=F16)
-        att = torch.empty(t, fh, fw, 512, device=dev, dtype=F16)
-        y = torch.empty(t, fh, fw, 512, device=dev, dtype=F16)
-        f1 = torch.empty(t, fh, fw, 1960, device=dev, dtype=F16)
-        f2 = torch.empty(t, fh, fw, 1960, device=dev, dtype=F16)
-        folded = torch.empty(t, h, w, 40, device=dev, dtype=F16)
+        xn = torch.zeros(t, Hp, Wp, 512, device=dev, dtype=self.dt)  # pad tokens stay zero (:212-216)
+        qkv = torch.empty(t, Hp, Wp, 1536, device=dev, dtype=self.dt)
+        pooled = torch.empty(t, ph, pw, 512, device=dev, dtype=self.dt)
+        pkv = torch.empty(t, ph, pw, 1024, device=dev, dtype=self.dt)
+        att = torch.empty(t, fh, fw, 512, device=dev, dtype=self.dt)
+        y = torch.empty(t, fh, fw, 512, device=dev, dtype=self.dt)
+        f1 = torch.empty(t, fh, fw, 1960, device=dev, dtype=self.dt)
+        f2 = torch.empty(t, fh, fw, 1960, device=dev, dtype=self.dt)
+        folded = torch.empty(t, h, w, 40, device=dev, dtype=self.dt)
         tok2 = torch.empty_like(tok)
         t_inds = [torch.arange(i, t, 2, dtype=torch.int32, device=dev) for i in (0, 1)]
         for i, B in enumerate(self.blocks):
@@ -287,32 +294,32 @@ class InpaintGeneratorMI355:
         dev = st.enc.device
         lt, t = len(nb), len(nb) + len(refs)
         _, h, w, _ = st.enc.shape
-        feat = torch.empty(t, h, w, 128, device=dev, dtype=F16)
+        feat = torch.empty(t, h, w, 128, device=dev, dtype=self.dt)
         if local_prop is None:
             local_prop = self.propagate_windows(st, [nb])[0]
         feat[:lt] = local_prop
         if refs:
             torch.index_select(st.enc, 0, ops.device_ints(refs, dev), out=feat[lt:])
         fh, fw = token_grid(h, w)
-        tok = torch.empty(t, fh, fw, 512, device=dev, dtype=F16)
+        tok = torch.empty(t, fh, fw, 512, device=dev, dtype=self.dt)
         ops.conv2d(self.ss, [feat], tok)
         flags = self.window_mask_flags(st, nb)
         if trace is not None:
             trace.update(local_prop=feat[:lt].clone(), tok=tok.clone())
         tok = self._transformer(tok, (h, w), flags)
         # soft composition + residual, only for the local frames that are decoded (:443-451)
-        emb = torch.empty(lt, fh, fw, 6272, device=dev, dtype=F16)
+        emb = torch.empty(lt, fh, fw, 6272, device=dev, dtype=self.dt)
         ops.conv2d(self.sc, [tok[:lt]], emb)
-        comp = torch.empty(lt, h, w, 128, device=dev, dtype=F16)
+        comp = torch.empty(lt, h, w, 128, device=dev, dtype=self.dt)
         ops.fold(emb.view(lt, fh * fw, 6272), comp, fh, fw, False)
-        enc3 = torch.empty(lt, h, w, 128, device=dev, dtype=F16)
+        enc3 = torch.empty(lt, h, w, 128, device=dev, dtype=self.dt)
         ops.conv2d(self.sc_bias_conv, [comp], enc3, epi="add", aux1=feat[:lt])
         if trace is not None:
             trace.update(tok_out=tok, enc3=enc3)
         H, W = st.H, st.W
 
         def new(hh, ww, c):
-            return torch.empty(lt, hh, ww, c, device=dev, dtype=F16)
+            return torch.empty(lt, hh, ww, c, device=dev, dtype=self.dt)
 
         up = ops.upsample2x(enc3, new(2 * h, 2 * w, 128))
         a = ops.conv2d(self.dec0, [up], new(2 * h, 2 * w, 128), act="leaky", act_param=0.2)

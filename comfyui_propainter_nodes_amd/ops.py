@@ -536,7 +536,7 @@ def img_prop_step(x_cur, m_cur, f_new, m_new, *, f_prev=None, m_prev=None, flow_
 
 
 def pack_encoder_input(frames, prop, m_in, m_upd, out, updated=None) -> torch.Tensor:
-    """frames/prop fp32 [T,H,W,3], masks u8 [T,H,W] -> out f16 [T,H,W,8] (+ updated fp32 [T,H,W,3])."""
+    """frames/prop fp32 [T,H,W,3], masks u8 [T,H,W] -> out f16 / f32 [T,H,W,8] (+ updated fp32 [T,H,W,3])."""
     check_device(frames, prop, m_in, m_upd, out, updated)
     for t in (frames, prop, m_in, m_upd, out):
         if not t.is_contiguous():
@@ -546,6 +546,7 @@ def pack_encoder_input(frames, prop, m_in, m_upd, out, updated=None) -> torch.Te
                                                 out.data_ptr())
     if updated is not None:
         P.updated = updated.data_ptr()
+    P.out_dtype = dtype_code(out.dtype)
     P.total_pixels = m_in.numel()
     _call("pp_pack_encoder_input", out, P)
     return out
@@ -573,6 +574,9 @@ def featprop_aux(flow_prop, flow_check, maskpair, out) -> torch.Tensor:
             raise ValueError("featprop_aux: tensors must be dense")
     P = _lib.STRUCTS["pp_featprop_aux_params"]()
     P.flow_prop, P.flow_check, P.maskpair, P.out = flow_prop.data_ptr(), flow_check.data_ptr(), maskpair.data_ptr(), out.data_ptr()
+    if maskpair.dtype != out.dtype:
+        raise TypeError("featprop_aux: maskpair and out must share a dtype")
+    P.dtype = dtype_code(out.dtype)
     P.N, P.H, P.W = n, h, w
     _call("pp_featprop_aux", out, P)
     return out
@@ -604,6 +608,9 @@ def layernorm(x: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: tor
         raise ValueError("layernorm: bad tensors")
     P = _lib.STRUCTS["pp_layernorm_params"]()
     P.x, P.out, P.gamma, P.beta = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    if x.dtype != out.dtype:
+        raise TypeError("layernorm: x and out must share a dtype")
+    P.dtype = dtype_code(x.dtype)
     P.T, P.fh, P.fw, P.Hp, P.Wp, P.C, P.eps = t, fh, fw, hp, wp, c, eps
     _call("pp_layernorm", out, P)
     return out
@@ -616,6 +623,9 @@ def pool_tokens(x: torch.Tensor, out: torch.Tensor, weight: torch.Tensor, bias: 
         raise ValueError("pool_tokens: bad tensors")
     P = _lib.STRUCTS["pp_pool_tokens_params"]()
     P.x, P.out, P.weight, P.bias = x.data_ptr(), out.data_ptr(), weight.data_ptr(), bias.data_ptr()
+    if x.dtype != out.dtype:
+        raise TypeError("pool_tokens: x and out must share a dtype")
+    P.dtype = dtype_code(x.dtype)
     P.T, P.Hp, P.Wp, P.C = t, hp, wp, c
     _call("pp_pool_tokens", out, P)
     return out
@@ -635,6 +645,9 @@ def window_attention(qkv: torch.Tensor, pkv: torch.Tensor, win_masked: torch.Ten
     P = _lib.STRUCTS["pp_window_attention_params"]()
     P.qkv, P.pkv, P.win_masked, P.t_ind, P.out = (qkv.data_ptr(), pkv.data_ptr(), win_masked.data_ptr(), t_ind.data_ptr(),
                                                   out.data_ptr())
+    if not (qkv.dtype == pkv.dtype == out.dtype):
+        raise TypeError("window_attention: qkv, pkv and out must share a dtype")
+    P.dtype = dtype_code(qkv.dtype)
     P.t, P.nt, P.Hp, P.Wp, P.fh, P.fw, P.npool = t, t_ind.numel(), hp, wp, fh, fw, pkv.shape[1]
     P.scale = 1.0 / (128 ** 0.5)
     _call("pp_window_attention", out, P)
@@ -649,6 +662,9 @@ def fold(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int, normalize: bool) 
         raise ValueError("fold: bad tensors")
     P = _lib.STRUCTS["pp_fold_params"]()
     setattr(P, "in", x.data_ptr())
+    if x.dtype != out.dtype:
+        raise TypeError("fold: x and out must share a dtype")
+    P.dtype = dtype_code(x.dtype)
     P.out, P.T, P.H, P.W, P.C, P.fh, P.fw, P.normalize = out.data_ptr(), t, h, w, c, fh, fw, int(normalize)
     _call("pp_fold", out, P)
     return out
@@ -662,6 +678,9 @@ def unfold_gelu(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int) -> torch.T
         raise ValueError("unfold_gelu: bad tensors")
     P = _lib.STRUCTS["pp_unfold_gelu_params"]()
     setattr(P, "in", x.data_ptr())
+    if x.dtype != out.dtype:
+        raise TypeError("unfold_gelu: x and out must share a dtype")
+    P.dtype = dtype_code(x.dtype)
     P.out, P.T, P.H, P.W, P.C, P.fh, P.fw = out.data_ptr(), t, h, w, c, fh, fw
     _call("pp_unfold_gelu", out, P)
     return out
@@ -673,7 +692,7 @@ def compose_u8(pred: torch.Tensor, frame_ids: torch.Tensor, first: torch.Tensor,
     check_device(pred, frame_ids, first, masks_u8, orig_u8, comp_u8)
     l, h, w, _ = pred.shape
     P = _lib.STRUCTS["pp_compose_u8_params"]()
-    P.pred, P.pred_ldc = pred.data_ptr(), pred.stride(2)
+    P.pred, P.pred_ldc, P.pred_dtype = pred.data_ptr(), pred.stride(2), dtype_code(pred.dtype)
     P.frame_ids, P.first, P.masks, P.orig, P.comp = (frame_ids.data_ptr(), first.data_ptr(), masks_u8.data_ptr(),
                                                      orig_u8.data_ptr(), comp_u8.data_ptr())
     P.L, P.H, P.W = l, h, w
@@ -748,17 +767,17 @@ def mask_dilate(mask: torch.Tensor, iterations: int) -> torch.Tensor:
     return out
 
 
-def clip_masks(m_in: torch.Tensor, m_upd: torch.Tensor, fh: int, fw: int):
-    """u8 masks [T,H,W] -> (maskpair f16 [T,H/4,W/4,8], tokmask u8 [T,fh,fw]) (propainter.py:409-428)."""
+def clip_masks(m_in: torch.Tensor, m_upd: torch.Tensor, fh: int, fw: int, dtype: torch.dtype = torch.float16):
+    """u8 masks [T,H,W] -> (maskpair f16 / f32 [T,H/4,W/4,8], tokmask u8 [T,fh,fw]) (propainter.py:409-428)."""
     check_device(m_in, m_upd)
     t, h, w = m_in.shape
     if not (m_in.is_contiguous() and m_upd.is_contiguous()) or m_in.dtype != torch.uint8 or m_upd.dtype != torch.uint8:
         raise ValueError("clip_masks: expected dense uint8 masks")
-    maskpair = torch.empty(t, h // 4, w // 4, 8, dtype=torch.float16, device=m_in.device)
+    maskpair = torch.empty(t, h // 4, w // 4, 8, dtype=dtype, device=m_in.device)
     tok = torch.empty(t, fh, fw, dtype=torch.uint8, device=m_in.device)
     P = _lib.STRUCTS["pp_clip_masks_params"]()
     P.m_in, P.m_upd, P.maskpair, P.tokmask = m_in.data_ptr(), m_upd.data_ptr(), maskpair.data_ptr(), tok.data_ptr()
-    P.T, P.H, P.W, P.fh, P.fw = t, h, w, fh, fw
+    P.T, P.H, P.W, P.fh, P.fw, P.dtype = t, h, w, fh, fw, dtype_code(dtype)
     _call("pp_clip_masks", tok, P)
     return maskpair, tok
 

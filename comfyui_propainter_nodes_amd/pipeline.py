@@ -99,10 +99,6 @@ def initialize_models(device: torch.device, use_half: str = "enable", seed: int 
     network access here).  When they are missing the node FAILS, as a user would otherwise get plausible-looking
     garbage; seeded synthetic weights are an explicit opt-in for benchmarks and tests
     (PP_ALLOW_SYNTHETIC_WEIGHTS=1)."""
-    if use_half == "disable":
-        _warn_once("fp16='disable': RAFT and flow completion run on fp32 tensors as in the reference; the generator keeps "
-                   "f16 storage with fp32 accumulation / statistics / coordinates in this build (>= 58 dB against the "
-                   "fp32 reference on the parity fixtures) - there is no fp32-storage mode for that network yet")
     if weights.weights_available():
         ident = tuple((f, (weights.WEIGHT_DIR / f).stat().st_size, (weights.WEIGHT_DIR / f).stat().st_mtime_ns)
                       for f in weights.FILES.values())
@@ -124,10 +120,11 @@ def initialize_models(device: torch.device, use_half: str = "enable", seed: int 
 
 
 def models_from_state_dicts(sds: dict, device, fp16: str = "enable", provenance: str = "explicit") -> Models:
-    """RAFT is fp32 in both modes (utils/model_utils.py:55-56); fp16 "disable" keeps flow completion in fp32 too."""
-    rfc_dtype = torch.float16 if fp16 == "enable" else torch.float32
-    return Models(RaftFlow(sds["raft"], device), FlowCompleter(sds["rfc"], device, rfc_dtype),
-                  InpaintGeneratorMI355(sds["gen"], device), provenance)
+    """RAFT is fp32 in both modes (utils/model_utils.py:55-56); fp16 "disable" keeps the other two networks on fp32
+    tensors as well (utils/model_utils.py:57-58 only calls .half() for "enable")."""
+    dt = torch.float16 if fp16 == "enable" else torch.float32
+    return Models(RaftFlow(sds["raft"], device), FlowCompleter(sds["rfc"], device, dt),
+                  InpaintGeneratorMI355(sds["gen"], device, dt), provenance)
 
 
 def compute_flow(raft_model: RaftFlow, frames: torch.Tensor, config: ProPainterConfig) -> torch.Tensor:
@@ -225,10 +222,10 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     mark("flow_completion")
     prop, upd = image_propagation(frames, md, pred, config)
     mark("image_propagation")
-    packed = torch.empty(T, H, W, 8, device=dev, dtype=torch.float16)
+    gen = models.inpaint_model
+    packed = torch.empty(T, H, W, 8, device=dev, dtype=gen.dt)
     updated = torch.empty(T, H, W, 3, device=dev) if trace is not None else None
     ops.pack_encoder_input(frames, prop, md, upd, packed, updated)
-    gen = models.inpaint_model
     st = gen.prepare_clip(packed, pred, md, upd)
     mark("encoder+clip_prep")
     comp = torch.zeros(T, H, W, 3, dtype=torch.uint8, device=dev)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 2
+#define PP_ABI_VERSION 3
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -325,6 +325,7 @@ typedef struct {
   void* out;
   void* updated;
   int64_t total_pixels;
+  int32_t out_dtype; /* PP_F16 or PP_F32: storage type of the generator's activations */
 } pp_pack_encoder_input_params;
 int32_t pp_pack_encoder_input(void* stream, const pp_pack_encoder_input_params* p);
 
@@ -352,6 +353,7 @@ typedef struct {
   const void* maskpair;
   void* out;
   int64_t N, H, W;
+  int32_t dtype; /* maskpair and out: PP_F16 or PP_F32 */
 } pp_featprop_aux_params;
 int32_t pp_featprop_aux(void* stream, const pp_featprop_aux_params* p);
 
@@ -383,6 +385,7 @@ typedef struct {
   const void* beta;  /* fp32 [C] */
   int64_t T, fh, fw, Hp, Wp, C;
   float eps;
+  int32_t dtype; /* x and out: PP_F16 or PP_F32 */
 } pp_layernorm_params;
 int32_t pp_layernorm(void* stream, const pp_layernorm_params* p);
 
@@ -397,6 +400,7 @@ typedef struct {
   const void* weight;
   const void* bias;
   int64_t T, Hp, Wp, C;
+  int32_t dtype; /* x and out: PP_F16 or PP_F32 */
 } pp_pool_tokens_params;
 int32_t pp_pool_tokens(void* stream, const pp_pool_tokens_params* p);
 
@@ -417,6 +421,7 @@ typedef struct {
   void* out;
   int64_t t, nt, Hp, Wp, fh, fw, npool;
   float scale;
+  int32_t dtype; /* qkv, pkv, out: PP_F16 or PP_F32 (fp32 storage is rounded to f16 for the MFMA operands) */
 } pp_window_attention_params;
 int32_t pp_window_attention(void* stream, const pp_window_attention_params* p);
 
@@ -433,6 +438,7 @@ typedef struct {
   void* out;      /* f16 [T][H][W][C] */
   int64_t T, H, W, C, fh, fw;
   int32_t normalize;
+  int32_t dtype; /* in and out: PP_F16 or PP_F32 */
 } pp_fold_params;
 int32_t pp_fold(void* stream, const pp_fold_params* p);
 
@@ -440,6 +446,7 @@ typedef struct {
   const void* in; /* f16 [T][H][W][C] */
   void* out;      /* f16 [T][fh*fw][49*C] */
   int64_t T, H, W, C, fh, fw;
+  int32_t dtype; /* in and out: PP_F16 or PP_F32 */
 } pp_unfold_gelu_params;
 int32_t pp_unfold_gelu(void* stream, const pp_unfold_gelu_params* p);
 
@@ -459,6 +466,7 @@ typedef struct {
   const void* orig;
   void* comp;
   int64_t L, H, W;
+  int32_t pred_dtype; /* PP_F16 or PP_F32 */
 } pp_compose_u8_params;
 int32_t pp_compose_u8(void* stream, const pp_compose_u8_params* p);
 
@@ -520,6 +528,7 @@ typedef struct {
   void* maskpair;
   void* tokmask;
   int64_t T, H, W, fh, fw;
+  int32_t dtype; /* maskpair: PP_F16 or PP_F32 */
 } pp_clip_masks_params;
 int32_t pp_clip_masks(void* stream, const pp_clip_masks_params* p);
 
