@@ -100,8 +100,13 @@ def _expand_masks(m: torch.Tensor, T: int) -> torch.Tensor:
 
 
 def _output(comp_u8: torch.Tensor, fm_u8: torch.Tensor, md_u8: torch.Tensor):
-    """handle_output (image_utils.py:276-290): IMAGE fp32 k/255 on the host, the two masks fp32 on the device."""
-    images = ops.image_from_u8(comp_u8).cpu()
+    """handle_output (image_utils.py:276-290): IMAGE fp32 k/255 on the host, the two masks fp32 on the device.
+    The uint8 frames cross PCIe (a quarter of the fp32 bytes) and become float32(k) / 255 on the host cores (the same
+    IEEE division as the reference's numpy expression); PP_OUTPUT=device converts on the GPU and copies fp32 instead."""
+    if os.environ.get("PP_OUTPUT") == "device":
+        images = ops.image_from_u8(comp_u8).cpu()
+    else:
+        images = comp_u8.cpu().to(torch.float32).div_(255.0)
     return images, fm_u8.float().squeeze(), md_u8.float().squeeze()
 
 

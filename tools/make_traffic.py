@@ -16,17 +16,20 @@ def family(path, sub):
 
 
 def main(fetch, write, out, *pairs):
-    fams = {}
-    for pair in pairs:
+    acc = {}
+    for pair in pairs:   # several kernel-name substrings may feed one profile key (flat + halo-tile + split-K kernels)
         sub, key = pair.split("=")
         nf, tf = family(fetch, sub)
         nw, tw = family(write, sub)
         if not nf or not nw:
             continue
-        fams[key] = {
-            "kernel": f"{sub} (all tile variants)", "dispatches": nf, "fetch_size_kb_avg": tf / nf, "write_size_kb_avg": tw / nw,
-            "hbm_bytes_per_launch": (2.0 * tf / nf + tw / nw) * 1024.0,
-        }
+        a = acc.setdefault(key, {"subs": [], "nf": 0, "tf": 0.0, "nw": 0, "tw": 0.0})
+        a["subs"].append(sub)
+        a["nf"] += nf; a["tf"] += tf; a["nw"] += nw; a["tw"] += tw
+    fams = {key: {"kernel": " + ".join(a["subs"]) + " (all tile variants)", "dispatches": a["nf"],
+                  "fetch_size_kb_avg": a["tf"] / a["nf"], "write_size_kb_avg": a["tw"] / a["nw"],
+                  "hbm_bytes_per_launch": (2.0 * a["tf"] / a["nf"] + a["tw"] / a["nw"]) * 1024.0}
+            for key, a in acc.items()}
     res = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over bench.py --steps 1 "
                   "--warmup 0; tools/profile_bench.sh",

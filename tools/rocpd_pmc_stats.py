@@ -13,7 +13,7 @@ def main(path, counter, out=None):
         a[0] += 1
         a[1] += v
     res = {name[:120]: {"dispatches": a[0], "avg": a[1] / a[0], "total": a[1]} for name, a in agg.items()}
-    res = dict(sorted(res.items(), key=lambda kv: -kv[1]["total"])[:25])
+    res = dict(sorted(res.items(), key=lambda kv: -kv[1]["total"])[:40])
     text = json.dumps({"counter": counter, "kernels": res}, indent=1)
     if out:
         open(out, "w").write(text + "\n")
