@@ -15,7 +15,7 @@ HOST_CLANG = os.environ.get("PP_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 def build_emu(force: bool = False) -> Path:
-    flags = ["-O2", "-std=c++17", "-fPIC", "-DPP_EMU", "-x", "c++", "-Wno-unused-value", "-ffp-contract=off",
+    flags = ["-O3", "-mavx2", "-mf16c", "-std=c++17", "-fPIC", "-DPP_EMU", "-x", "c++", "-Wno-unused-value", "-ffp-contract=off",
              "-I", str(B.CSRC), "-I", str(B.ROOT / "include"), "-I", str(EMU_DIR)]
 
     def compile_one(src: Path, obj: Path) -> None:

@@ -56,8 +56,3 @@ def test_generator_window_matches_oracle(hip_lib, dtype, tol_mid, tol_tok, tol_i
     """f16 storage (fp16 "enable") and f32 storage (fp16 "disable": encoder / propagation to fp32 rounding noise; tokens and
     image carry the f16 rounding of the attention core's MFMA operands)."""
     _run("cuda:0", dtype, 128, 144, 4, 6, tol_mid, tol_tok, tol_img)
-
-
-def test_generator_window_f32_under_emulation(emu_lib):
-    """The fp32-storage generator (fp16 "disable") through the kernel emulator at the smallest useful size."""
-    _run("cpu", torch.float32, 64, 72, 2, 3, 2e-5, 2e-3, 2e-3)

@@ -1,4 +1,5 @@
 """Flow-guided propagation kernels against the oracle (fp32 CPU restatement of the reference)."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -30,7 +31,8 @@ def test_image_propagation_bit_exact(backend):
     assert torch.equal(pf.cpu(), rf[0].permute(0, 2, 3, 1))
 
 
-def test_flow_down4_aux_and_warp(backend):
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32], ids=["f16", "f32"])
+def test_flow_down4_aux_and_warp(backend, dt):
     dev = backend
     g = torch.Generator().manual_seed(22)
     n, H, W = 3, 32, 48
@@ -44,17 +46,17 @@ def test_flow_down4_aux_and_warp(backend):
     # fb-check planes + bilinear feature warp at 1/4 resolution
     h, w = H // 4, W // 4
     dsf, dsb = ref, F.interpolate(flows[1], scale_factor=0.25, mode="bilinear", align_corners=False) / 4.0
-    mp = torch.zeros(n, h, w, 8, dtype=torch.float16)
-    mp[..., 0] = (torch.rand(n, h, w, generator=g) > 0.5).half()
-    mp[..., 1] = (torch.rand(n, h, w, generator=g) > 0.5).half()
-    aux = torch.empty(n, h, w, 8, device=dev, dtype=torch.float16)
+    mp = torch.zeros(n, h, w, 8, dtype=dt)
+    mp[..., 0] = (torch.rand(n, h, w, generator=g) > 0.5).to(dt)
+    mp[..., 1] = (torch.rand(n, h, w, generator=g) > 0.5).to(dt)
+    aux = torch.empty(n, h, w, 8, device=dev, dtype=dt)
     a = dsf.permute(0, 2, 3, 1).contiguous()
     b = dsb.permute(0, 2, 3, 1).contiguous()
     ops.featprop_aux(a.to(dev), b.to(dev), mp.to(dev), aux)
     valid = OG.fb_check(dsf, dsb)
     got = aux.float().cpu()
     assert torch.equal(got[..., 2], valid[:, 0])
-    assert torch.allclose(got[..., 0:2], a.half().float()) and torch.equal(got[..., 3:5], mp[..., 0:2].float())
+    assert torch.allclose(got[..., 0:2], a.to(dt).float()) and torch.equal(got[..., 3:5], mp[..., 0:2].float())
     x = torch.randn(n, h, w, 16, generator=g)
     out = torch.empty(n, h, w, 16, device=dev)
     ops.flow_warp(x.to(dev), a.to(dev), out)
@@ -62,7 +64,8 @@ def test_flow_down4_aux_and_warp(backend):
     assert torch.allclose(out.cpu(), refw, atol=1e-5)
 
 
-def test_pack_encoder_input(backend):
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32], ids=["f16", "f32"])
+def test_pack_encoder_input(backend, dt):
     dev = backend
     g = torch.Generator().manual_seed(23)
     T, H, W = 2, 8, 8
@@ -70,12 +73,12 @@ def test_pack_encoder_input(backend):
     prop = torch.rand(T, H, W, 3, generator=g) * 2 - 1
     m_in = (torch.rand(T, H, W, generator=g) > 0.5).to(torch.uint8)
     m_up = (torch.rand(T, H, W, generator=g) > 0.5).to(torch.uint8)
-    out = torch.empty(T, H, W, 8, device=dev, dtype=torch.float16)
+    out = torch.empty(T, H, W, 8, device=dev, dtype=dt)
     upd = torch.empty(T, H, W, 3, device=dev)
     ops.pack_encoder_input(frames.to(dev), prop.to(dev), m_in.to(dev), m_up.to(dev), out, upd)
     m = m_in.float()[..., None]
     ref = frames * (1 - m) + prop * m
     assert torch.equal(upd.cpu(), ref)
     got = out.float().cpu()
-    assert torch.equal(got[..., :3], ref.half().float()) and torch.equal(got[..., 3], m_in.float()) and torch.equal(got[..., 4], m_up.float())
+    assert torch.equal(got[..., :3], ref.to(dt).float()) and torch.equal(got[..., 3], m_in.float()) and torch.equal(got[..., 4], m_up.float())
     assert torch.all(got[..., 5:] == 0)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Ablation builds of the halo-tile kernels: whole library with conv_halo.hip compiled -DPP_ABLATE=<mask> (1 no MFMA, 2 no pixel
+# Ablation builds of the halo-tile kernels: whole library with conv_halo.hip / conv_halo_f16.hip compiled -DPP_ABLATE=<mask> (1 no MFMA, 2 no pixel
 # loads, 4 no weight copies, 16 no LDS fragment reads, 32 no barriers).  --build here (CPU); without arguments on the MI355X:
 # convbench against every variant (results of an ablated kernel are meaningless; only the time differences are read).
 cd "$(dirname "$0")/.."
@@ -7,11 +7,13 @@ PKG=comfyui_propainter_nodes_amd
 if [ "${1:-}" = "--build" ]; then
   for m in 1 2 4 6 16 32; do
     mkdir -p tools/ablate/$m
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPP_ABLATE=$m -I $PKG/csrc -I include -c $PKG/csrc/conv_halo.hip -o tools/ablate/$m/conv_halo.o &
+    for f in conv_halo conv_halo_f16; do
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPP_ABLATE=$m -I $PKG/csrc -I include -c $PKG/csrc/$f.hip -o tools/ablate/$m/$f.o &
+    done
   done; wait
   for m in 1 2 4 6 16 32; do
-    objs=$(ls $PKG/build/hip/*.o | grep -v conv_halo.o)
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs tools/ablate/$m/conv_halo.o -o tools/ablate/$m/libpropainter_mi355.so && rm tools/ablate/$m/conv_halo.o
+    objs=$(ls $PKG/build/hip/*.o | grep -v "conv_halo.o\|conv_halo_f16.o")
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs tools/ablate/$m/conv_halo.o tools/ablate/$m/conv_halo_f16.o -o tools/ablate/$m/libpropainter_mi355.so && rm tools/ablate/$m/*.o
   done; ls -la tools/ablate/*/; exit 0
 fi
 O=gpurun_out/ablate_halo; mkdir -p $O
