@@ -48,6 +48,7 @@ extern "C" int64_t pp_struct_size(const char* name) {
   if (!name) return -1;
   PP_SIZEOF_CASE(pp_conv2d_params)
   PP_SIZEOF_CASE(pp_im2col_params)
+  PP_SIZEOF_CASE(pp_split_pack_params)
   PP_SIZEOF_CASE(pp_instnorm_params)
   PP_SIZEOF_CASE(pp_avgpool2x2_params)
   PP_SIZEOF_CASE(pp_corr_lookup_params)

@@ -65,6 +65,33 @@ __global__ void __launch_bounds__(256) im2col_kernel(const TI* __restrict__ in, 
 }
 
 // ----------------------------------------------------------------------------------------
+// PP_F32X2 operand packing of an ACTIVATION matrix that plays the weight role (the all-pairs volume: both operands are
+// feature maps): every 32-float chunk of a row becomes 32 f16 h = f16_rtz(v) followed by 32 f16 l = f16(sat((v-h)*2048)),
+// the layout pp_conv2d(PP_F32X2) expects for its A operand (host: ops.split_pack_weight).  One thread = 8 values.
+// ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t total8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over rows*K/8
+  if (i >= total8) return;
+  const f4 a = *reinterpret_cast<const f4*>(in + i * 8), b = *reinterpret_cast<const f4*>(in + i * 8 + 4);
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  h8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const h2 hh = cvt_pkrtz_f16(v[e], v[e + 1]);
+    h[e] = hh[0];
+    h[e + 1] = hh[1];
+    const float r0 = (v[e] - (float)hh[0]) * 2048.f, r1 = (v[e + 1] - (float)hh[1]) * 2048.f;
+    l[e] = (half_t)fminf(fmaxf(r0, -65504.f), 65504.f);
+    l[e + 1] = (half_t)fminf(fmaxf(r1, -65504.f), 65504.f);
+  }
+  const int64_t chunk = i >> 2;            // 32-value chunk = 4 octets
+  const int oct = (int)(i & 3);
+  half_t* base = out + chunk * 64;         // 64 halves (128 bytes) per chunk
+  *reinterpret_cast<h8*>(base + oct * 8) = h;
+  *reinterpret_cast<h8*>(base + 32 + oct * 8) = l;
+}
+
+// ----------------------------------------------------------------------------------------
 // instance norm (channels-last fp32): partial sums in double, then fused apply
 // ----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) instnorm_partial_kernel(const float* __restrict__ x, int x_ldc, int64_t HW,
@@ -334,6 +361,15 @@ extern "C" int32_t pp_im2col(void* stream, const pp_im2col_params* p) {
   }
 #undef PP_IM2COL
   return pp_check_launch("pp_im2col");
+}
+
+extern "C" int32_t pp_split_pack(void* stream, const pp_split_pack_params* p) {
+  using namespace pp;
+  if (!p || !p->in || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_split_pack: null argument");
+  if (p->rows <= 0 || p->K <= 0 || p->K % 32) return pp_fail(PP_ERR_BAD_ARG, "pp_split_pack: K must be a positive multiple of 32");
+  const int64_t total8 = p->rows * p->K / 8;
+  PP_LAUNCH(split_pack_kernel, dim3(blocks_for(total8)), dim3(256), 0, stream, (const float*)p->in, (half_t*)p->out, total8);
+  return pp_check_launch("pp_split_pack");
 }
 
 extern "C" int32_t pp_instnorm(void* stream, const pp_instnorm_params* p) {

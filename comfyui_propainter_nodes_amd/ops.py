@@ -314,14 +314,30 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
     return out
 
 
-def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float = 0.0) -> torch.Tensor:
+def split_pack(b: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., K] (K % 32 == 0, dense) -> the PP_F32X2 weight packing of the same shape (an f32-typed bit container)."""
+    check_device(b)
+    if b.dtype != torch.float32 or not b.is_contiguous() or b.shape[-1] % 32:
+        raise ValueError("split_pack: expected a dense fp32 tensor with K % 32 == 0")
+    out = torch.empty_like(b)
+    P = _lib.STRUCTS["pp_split_pack_params"]()
+    setattr(P, "in", b.data_ptr())
+    P.out, P.rows, P.K = out.data_ptr(), b.numel() // b.shape[-1], b.shape[-1]
+    _call("pp_split_pack", out, P)
+    return out
+
+
+def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float = 0.0, split: bool = False) -> torch.Tensor:
     """out[z, 0, m, n] = scale * sum_k a[z, 0, m, k] * b[z, n, k]  (pp_conv2d with gridDim.z = batch).
 
     a: [Z, 1, M, K] channels-last "image" of M pixels, b: [Z, N, K] per-batch "weights"
     (K a multiple of 32), out: [Z, 1, M, N].  Used for the RAFT all-pairs volume (corr.py:52-60).
+    `split` (fp32 only): PP_F32X2 products -- b is packed on the device (pp_split_pack), a is split inside the kernel.
     """
     L = _lib.current()
     check_device(a, b, out)
+    if split and a.dtype == torch.float32:
+        b = split_pack(b)
     z, one, m, k = a.shape
     zb, n, kb = b.shape
     if one != 1 or zb != z or kb != k or k % 32 != 0 or not b.is_contiguous():
@@ -329,7 +345,7 @@ def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: 
     if tuple(out.shape) != (z, 1, m, n):
         raise ValueError("batched_gemm_nt: bad output shape")
     P = _lib.STRUCTS["pp_conv2d_params"]()
-    P.dtype = dtype_code(a.dtype)
+    P.dtype = _lib.CONSTS["PP_F32X2"] if (split and a.dtype == torch.float32) else dtype_code(a.dtype)
     P.out_dtype = dtype_code(out.dtype)
     P.nseg = 1
     P.in_ptr[0] = a.data_ptr()
@@ -347,8 +363,9 @@ def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: 
     P.out_zoff = out.stride(0)
     P.out_scale = scale
     if CONV_PROFILE is not None and out.is_cuda:
-        CONV_PROFILE.launch("f16" if a.dtype == torch.float16 else "f32", 2.0 * z * m * n * k,
-                            lambda: L.call("pp_conv2d", stream_handle(out), P))
+        key = "f16" if a.dtype == torch.float16 else ("f32x2" if split else "f32")
+        CONV_PROFILE.launch(key, 2.0 * z * m * n * k, lambda: L.call("pp_conv2d", stream_handle(out), P),
+                            float(a.numel() + b.numel() + out.numel()) * a.element_size())
     else:
         L.call("pp_conv2d", stream_handle(out), P)
     return out

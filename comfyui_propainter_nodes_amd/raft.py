@@ -178,7 +178,8 @@ class RaftFlow:
         P, h, w, _ = ctx.shape
         hw = h * w
         vol = torch.empty(P, 1, hw, hw, device=dev)
-        ops.batched_gemm_nt(f1.view(P, 1, hw, 256), f2, vol, scale=1.0 / 16.0)  # corr.py:52-60 (/sqrt(256))
+        # corr.py:52-60 (/sqrt(256)); both operands are activations: f2 is split-packed on the device (PP_F32X2)
+        ops.batched_gemm_nt(f1.view(P, 1, hw, 256), f2, vol, scale=1.0 / 16.0, split=ops.f32_split_enabled())
         pyr = [vol.view(P, hw, h, w)]
         for _ in range(3):
             ph, pw = pyr[-1].shape[2] // 2, pyr[-1].shape[3] // 2

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 3
+#define PP_ABI_VERSION 4
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -127,6 +127,19 @@ typedef struct {
 } pp_conv2d_params;
 
 int32_t pp_conv2d(void* stream, const pp_conv2d_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_split_pack -- PP_F32X2 packing of an fp32 matrix [rows][K] (K % 32 == 0) that will be the WEIGHT operand of
+ * pp_conv2d(PP_F32X2): the all-pairs correlation volume (corr.py:52-60) multiplies two activation tensors, so the
+ * packing the host does once for constant weights (ops.split_pack_weight) runs on the device per clip.
+ * out: same byte size, every 32-float chunk -> 32 f16 h | 32 f16 l.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const void* in;
+  void* out;
+  int64_t rows, K;
+} pp_split_pack_params;
+int32_t pp_split_pack(void* stream, const pp_split_pack_params* p);
 
 /* ------------------------------------------------------------------------------------
  * pp_im2col -- explicit patch matrix for the few convolutions whose Cin is too small for

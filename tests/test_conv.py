@@ -343,6 +343,14 @@ def test_conv2d_replicate_pad_and_batched_gemm(backend):
     ops.batched_gemm_nt(f1.to(dev), f2.to(dev), vol, scale=1.0 / 16)
     ref = torch.einsum("bpc,bqc->bpq", f1[:, 0], f2) / 16
     assert torch.allclose(vol.cpu()[:, 0], ref, atol=1e-5)
+    # ... with PP_F32X2 products: f2 is packed on the device into the layout the host gives constant weights
+    # (32 h | 32 l per chunk; h rounded toward zero here, to nearest on the host: both reconstruct v to 2^-22)
+    f1w, f2w = f1 * torch.logspace(-3, 2, 32), f2 * torch.logspace(2, -3, 32)   # wide dynamic range
+    pk = ops.split_pack(f2w.contiguous().to(dev)).cpu().view(torch.float16).view(3, 40, 64).float()
+    assert ((pk[..., :32] + pk[..., 32:] / 2048.0) - f2w).abs().max().item() <= 2.0 ** -21 * f2w.abs().max().item()
+    ops.batched_gemm_nt(f1w.contiguous().to(dev), f2w.contiguous().to(dev), vol, scale=1.0 / 16, split=True)
+    ref = torch.einsum("bpc,bqc->bpq", f1w[:, 0].double(), f2w.double()) / 16
+    assert (vol.cpu()[:, 0].double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
 
 
 if __name__ == "__main__":  # child process of test_conv2d_matches_torch

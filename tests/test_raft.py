@@ -64,3 +64,38 @@ def test_raft_split_gemm_matches_exact_f32_gemm(hip_lib, monkeypatch):
     assert torch.isfinite(fs).all() and torch.isfinite(bs).all()
     assert (fs - fe).abs().max().item() < 1e-3, (fs - fe).abs().max().item()
     assert (bs - be).abs().max().item() < 1e-3
+
+
+@pytest.mark.gpu
+def test_raft_stress_undamped_weights_large_motion(hip_lib, monkeypatch):
+    """The synthetic weights keep RAFT's flow head damped (weights.py: flow_head.conv2 gain 0.1, sub-pixel updates).  Here
+    the head is UN-damped (gain 1.0: updates of several pixels per iteration, the correlation windows leave the image, the
+    1/8-res flow reaches tens of px) on a clip with 20-px motion, 12 iterations: PP_F32X2 against the exact-f32 MFMA kernels
+    and against the fp32 oracle.  The update loop amplifies rounding differences when the head is un-damped, so the bounds
+    are relative to the flow magnitude (which the test also checks is large)."""
+    sds = weights.synth_state_dicts(0)
+    sd = dict(sds["raft"])
+    for k in sd:
+        if "flow_head.conv2.weight" in k:
+            sd[k] = sd[k] * 10.0
+    g = torch.Generator().manual_seed(3)
+    base = torch.rand(1, 3, 40, 40, generator=g)
+    base = torch.nn.functional.interpolate(base, size=(200, 200), mode="bicubic", align_corners=False).clamp(0, 1)[0]
+    frames = torch.stack([base[:, 20 + 20 * i:148 + 20 * i, 10 + 12 * i:138 + 12 * i].permute(1, 2, 0) for i in range(3)], 0)
+    frames = (frames * 2 - 1).contiguous()
+    iters = 12
+    monkeypatch.setenv("PP_F32_GEMM", "exact")
+    fe, be = raft.RaftFlow(sd, "cuda:0")(frames.cuda(), iters)
+    monkeypatch.setenv("PP_F32_GEMM", "split")
+    fs, bs = raft.RaftFlow(sd, "cuda:0")(frames.cuda(), iters)
+    fr = frames.permute(0, 3, 1, 2)
+    with torch.no_grad():
+        o = OR.raft_forward(sd, fr[0:1], fr[1:2], iters)[0].permute(1, 2, 0)
+    mag = float(o.abs().max())
+    e_se = float((fs - fe).abs().max())
+    e_so = float((fs[0].cpu() - o).abs().max())
+    e_eo = float((fe[0].cpu() - o).abs().max())
+    print(f"stress: |flow| max {mag:.1f} px; split-exact {e_se:.2e}, split-oracle {e_so:.2e}, exact-oracle {e_eo:.2e} px")
+    assert torch.isfinite(fs).all() and torch.isfinite(bs).all()
+    assert mag > 5.0
+    assert e_so <= max(2e-3, 5.0 * e_eo) and e_se <= max(2e-3, 5.0 * e_eo)   # the split is as close to the oracle as exact f32 is
