@@ -298,6 +298,305 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_kernel(const 
   });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Compile-time-tap form (KH x KW known, dilation 1: RAFT's 3x3, 1x5 and 5x1 convolutions).
+//
+// Measured model behind it (profiles/r02_conv_counters.md, r02_halo_ablation.md): a wave's MFMAs (16 cycles each) and its
+// other vector instructions (4 cycles each) add up on the SIMD -- cutting the flat kernel's vector instructions by 38 %
+// bought exactly the predicted 0.33 ms on the 3x3 256->192 convolution -- and the runtime-tap halo kernel still issues
+// ~120 vector + ~90 scalar instructions around the 48 MFMAs of a tap: fragment addresses (row, swizzle, shift per fragment
+// and tap), 64-bit weight addresses per copy, v_readfirstlane for every LDS-DMA destination, the tap / segment iterators.
+// Here
+//  * the taps are unrolled, so the pixel-fragment address of (tile row b, tap) is ONE per-lane base register plus an
+//    immediate offset: the pixel tile uses a padded 160-byte row pitch instead of an XOR swizzle (brute-forced: pitch
+//    160 is conflict-free for 16 consecutive rows at any start row against the ds_read_b128 service groups; 144 / 176 /
+//    192 are 2-way), and the weight fragments sit on aligned rows (XOR swizzle folded into the per-lane base);
+//  * the weight copies use a scalar running pointer plus per-lane 32-bit offsets (no 64-bit vector adds), the wave index is
+//    read into a scalar register once, so the LDS-DMA destinations (M0) are scalar arithmetic;
+//  * the pipeline decisions (which tap fetches the next pixel tile, which one stores it, the counted waits) are resolved at
+//    compile time.
+template <int WC, int WP, int TC, int TP, int KH, int KW>
+__global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_ct_kernel(const ConvK p, const HaloGeom g) {
+  typedef float OT;
+  constexpr int NT = WC * WP * 64;
+  constexpr int TH = WP * TP;
+  constexpr int XROWS = NT / 4, WROWS = NT / 8;
+  constexpr int BC = WC * TC * 16;
+  constexpr int BCP = (BC + WROWS - 1) / WROWS * WROWS;
+  constexpr int ROWB = 128;                      // weight rows
+  constexpr int XP = 160;                        // padded pixel-row pitch (bytes): conflict-free at any start row
+  constexpr int HW = kHaloTW + KW - 1;           // halo tile width
+  constexpr int HROWS = (TH + KH - 1) * HW;
+  constexpr int XPASS = (HROWS + XROWS - 1) / XROWS;
+  constexpr int WPASS = BCP / WROWS;
+  constexpr int XBYTES = XPASS * XROWS * XP, WSTAGE = BCP * ROWB;
+  constexpr int NX = 2 * XPASS;
+  constexpr int NTAPS = KH * KW;
+  constexpr float LINV = 1.f / 2048.f;
+  static_assert(TH == 8 && NTAPS >= 2 && HROWS <= kHaloMaxRows, "geometry");
+
+  unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+#ifdef PP_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations become scalar arithmetic
+#endif
+  const int wc = wave / WP;
+  const int wp = wave % WP;
+  const int z = (int)blockIdx.z;
+  int L;
+  {
+    const int nwg = (int)gridDim.x, id = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int ct = L % g.nct;
+  const int pt = L / g.nct;
+  const int txi = pt % g.tiles_x;
+  const int tyi = (pt / g.tiles_x) % g.tiles_y;
+  const int n = pt / (g.tiles_x * g.tiles_y);
+  const int ty0 = tyi * TH, tx0 = txi * kHaloTW;
+  const int c_base = ct * BC;
+
+  auto swz = [](int r) PP_INLINE_LAMBDA { return ((r >> 1) & 7) ^ ((r & 1) << 2); };  // weight rows (aligned fragments)
+
+  // weights: scalar running pointer + per-lane element offsets
+  const int pc = tid & 7;
+  const int wrow0 = tid >> 3;
+  const int pcs = pc ^ swz(wrow0);
+  const float* wptr = reinterpret_cast<const float*>(p.weight) + (int64_t)z * p.w_zoff;
+  uint32_t wlane[WPASS];                        // unsigned BYTE offsets: scalar base + 32-bit lane offset addressing
+#pragma unroll
+  for (int i = 0; i < WPASS; ++i) {
+    const int co = c_base + wrow0 + i * WROWS;
+    wlane[i] = (uint32_t)((co < p.Cout ? co : p.Cout - 1) * p.Kp + pcs * 4) * 4u;
+  }
+  // pixels
+  const int xj = tid & 3;
+  const int xrow0 = tid >> 2;
+  int xpix[XPASS];
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) {
+    const int hr = xrow0 + i * XROWS;
+    const int hy = hr / HW, hx = hr - hy * HW;
+    const int iy = ty0 - p.ph + hy, ix = tx0 - p.pw + hx;
+    const bool ok = hr < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    xpix[i] = ok ? (n * p.H + iy) * p.W + ix : -1;
+  }
+  f4 xreg[XPASS][2];
+  int xok = 0;
+
+  // K iterators
+  int w_rem = 0, w_seg = 0, w_sbase = 0, w_chunks = p.seg_chunks[0];
+  const int tapstride = p.chunks_per_tap * 32;
+  auto fetch_w = [&](int wbuf, int tap) PP_INLINE_LAMBDA {  // weights of (the iterator's chunk, tap) -> ring stage wbuf
+    unsigned char* wt = smem + XBYTES + wbuf * WSTAGE;
+    const char* src = reinterpret_cast<const char*>(wptr + (tap * tapstride + w_sbase + w_rem * 32));
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i) glds16(src + (size_t)wlane[i], wt + (i * NT + wave * 64) * 16);
+  };
+  auto w_next_chunk = [&]() PP_INLINE_LAMBDA {
+    if (++w_rem == w_chunks) {
+      w_rem = 0;
+      w_sbase += w_chunks * 32;
+      ++w_seg;
+#pragma unroll
+      for (int s = 1; s < PP_MAX_SEG; ++s)
+        if (w_seg == s) w_chunks = p.seg_chunks[s];
+    }
+  };
+  int x_rem = 0, x_seg = 0;
+  const float* x_base = reinterpret_cast<const float*>(p.in_ptr[0]) + (int64_t)z * p.in_zoff[0];
+  int x_C = p.in_C[0], x_ldc = p.in_ldc[0], x_chunks = p.seg_chunks[0];
+  auto fetch_x = [&]() PP_INLINE_LAMBDA {
+    const int c0 = x_rem * 32 + xj * 8;
+    int okbits = 0;
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      const bool ok0 = xpix[i] >= 0 && c0 < x_C, ok1 = xpix[i] >= 0 && c0 + 4 < x_C;
+      // unsigned 32-bit byte offsets from a scalar base (the launcher checks N*H*W*ldc < 2^30 elements): no 64-bit
+      // per-lane address arithmetic and no 64-bit loop invariants to keep in registers
+      const uint32_t off = ok0 ? (uint32_t)(xpix[i] * x_ldc + c0) * 4u : 0u;
+      gload16_hidden_s(xreg[i][0], x_base, off);
+      gload16_hidden_s(xreg[i][1], x_base, off + (ok1 ? 16u : 0u));
+      okbits |= ((ok0 ? 1 : 0) | (ok1 ? 2 : 0)) << (2 * i);
+    }
+    xok = okbits;
+    if (++x_rem == x_chunks) {
+      x_rem = 0;
+      ++x_seg;
+#pragma unroll
+      for (int s = 1; s < PP_MAX_SEG; ++s) {
+        if (x_seg == s && s < p.nseg) {
+          x_base = reinterpret_cast<const float*>(p.in_ptr[s]) + (int64_t)z * p.in_zoff[s];
+          x_C = p.in_C[s];
+          x_ldc = p.in_ldc[s];
+          x_chunks = p.seg_chunks[s];
+        }
+      }
+    }
+  };
+  auto store_x = [&]() PP_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      if (XPASS * XROWS > HROWS + XROWS - 1 && xrow0 + i * XROWS >= XPASS * XROWS) continue;
+      f4 v[2] = {xreg[i][0], xreg[i][1]};
+      if (!((xok >> (2 * i)) & 1)) v[0] = f4{0.f, 0.f, 0.f, 0.f};
+      if (!((xok >> (2 * i)) & 2)) v[1] = f4{0.f, 0.f, 0.f, 0.f};
+      h8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
+        const h2 hh = cvt_pkrtz_f16(c0, c1);
+        h[e] = hh[0];
+        h[e + 1] = hh[1];
+        l[e] = (half_t)split_lo(c0, (float)hh[0]);
+        l[e + 1] = (half_t)split_lo(c1, (float)hh[1]);
+      }
+      unsigned char* rowp = smem + (xrow0 + i * XROWS) * XP + xj * 16;
+      *reinterpret_cast<h8*>(rowp) = h;
+      *reinterpret_cast<h8*>(rowp + 64) = l;
+    }
+  };
+
+  f4 acc[TC][TP], accx[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+      accx[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+  const int frow = lane & 15;
+  const int fgrp = lane >> 4;
+  // per-lane fragment bases; everything else of a fragment address is an immediate
+  const unsigned char* xfrag = smem + (wp * TP * HW + frow) * XP + fgrp * 16;
+  const unsigned char* wfrag_h = smem + XBYTES + (wc * TC * 16 + frow) * ROWB + ((fgrp ^ swz(frow)) << 4);
+  const unsigned char* wfrag_l = smem + XBYTES + (wc * TC * 16 + frow) * ROWB + (((fgrp + 4) ^ swz(frow)) << 4);
+
+  auto compute = [&](auto tapc, int wbuf) PP_INLINE_LAMBDA {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int tapoff = (tap / KW) * HW + (tap % KW);
+    const unsigned char* wh = wfrag_h + wbuf * WSTAGE;
+    const unsigned char* wl = wfrag_l + wbuf * WSTAGE;
+    h8 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a) {
+      ah[a] = lds_frag(wh + a * 16 * ROWB);
+      al[a] = lds_frag(wl + a * 16 * ROWB);
+    }
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      bh[b] = lds_frag(xfrag + (b * HW + tapoff) * XP);
+      bl[b] = lds_frag(xfrag + (b * HW + tapoff) * XP + 64);
+    }
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bh[b], acc[a][b]);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(ah[a], bl[b], accx[a][b]);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(al[a], bh[b], accx[a][b]);
+  };
+
+  // ---- pipeline: step q = chunk * NTAPS + tap, weights of step q in ring stage q % 3 ----
+  const int nck = p.chunks_per_tap;
+  fetch_x();
+  fetch_w(0, 0);
+  fetch_w(1, 1);                               // NTAPS >= 2: steps 0 and 1 are taps 0 and 1 of chunk 0
+  wait_vmcnt_hidden<2 * WPASS>();
+  store_x();
+  wait_vmcnt_hidden<WPASS>();
+  pp_wait_lgkm0();
+  pp_barrier();
+  int w0 = 0;                                  // ring stage of the current step
+  for (int chunk = 0; chunk < nck; ++chunk) {
+    const bool next_chunk = chunk + 1 < nck;
+    static_for<NTAPS>([&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      constexpr bool pre_last = tap == NTAPS - 2, last = tap == NTAPS - 1;
+      const int w1 = w0 == 2 ? 0 : w0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;
+      // weights two steps ahead: tap + 2 of this chunk, or tap + 2 - NTAPS of the next one
+      const bool more_w = (tap + 2 < NTAPS) || next_chunk;
+      if (more_w) {
+        if constexpr (tap + 2 == NTAPS) w_next_chunk();  // the iterator moves on when the look-ahead crosses the chunk end
+        fetch_w(w2, (tap + 2) % NTAPS);
+      }
+      if constexpr (pre_last) {
+        if (next_chunk) fetch_x();
+      }
+      compute(tapc, w0);
+      if constexpr (last) {
+        if (next_chunk) {
+          pp_wait_lgkm0();
+          pp_barrier();                        // every wave has read its last fragments of the current pixel tile
+          wait_vmcnt_hidden<WPASS>();          // queue: [weights q+1] [pixels] [weights q+2]: retire up to the pixels
+          store_x();
+        } else {
+          wait_vmcnt_hidden<0>();
+        }
+      } else if constexpr (pre_last) {
+        // queue: [weights q+1] [weights q+2] [pixels]: weights q+1 must have landed
+        if (next_chunk) wait_vmcnt_hidden<WPASS + NX>(); else wait_vmcnt_hidden<0>();
+      } else {
+        if (more_w) wait_vmcnt_hidden<WPASS>(); else wait_vmcnt_hidden<0>();
+      }
+      pp_wait_lgkm0();
+      pp_barrier();
+#ifndef PP_EMU
+      __builtin_amdgcn_sched_barrier(0);       // unrolled taps: keep the next tap's address arithmetic / reads out of this one
+#endif
+      w0 = w1;
+    });
+  }
+
+  EpiCtx<OT> e;
+  e.bias = p.bias ? p.bias + (int64_t)z * p.bias_zoff : nullptr;
+  e.out = reinterpret_cast<OT*>(p.out) + (int64_t)z * p.out_zoff;
+  e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
+  e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
+  e.pre = reinterpret_cast<const OT*>(p.pre_add);
+  const int ox = tx0 + frow;
+  static_for<TP>([&](auto bi) {
+    constexpr int b = decltype(bi)::value;
+    const int oy = ty0 + wp * TP + b;
+    const int64_t m = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
+    const bool inside = oy < p.Ho && ox < p.Wo;
+    static_for<TC>([&](auto ai) {
+      constexpr int a = decltype(ai)::value;
+      const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
+      const f4 v = acc[a][b] + accx[a][b] * LINV;
+      if (inside && c < p.Cout) store_quad<OT>(p, e, v, m, c);
+    });
+  });
+}
+
+template <int WC, int WP, int TC, int TP, int KH, int KW>
+static int launch_halo_ct_cfg(void* stream, const ConvK& k, int Z, HaloGeom g) {
+  constexpr int BC = WC * TC * 16;
+  constexpr int NT = WC * WP * 64;
+  constexpr int BCP = (BC + NT / 8 - 1) / (NT / 8) * (NT / 8);
+  constexpr int HROWS = (8 + KH - 1) * (kHaloTW + KW - 1);
+  constexpr int XPASS = (HROWS + NT / 4 - 1) / (NT / 4);
+  const size_t smem = (size_t)XPASS * (NT / 4) * 160 + (size_t)3 * BCP * 128;
+  g.nct = (k.Cout + BC - 1) / BC;
+  dim3 grid((unsigned)(g.ntiles * g.nct), 1u, (unsigned)Z);
+  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), smem), true);
+  (void)lds_ok;
+  PP_LAUNCH((conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), grid, dim3(NT), smem, stream, k, g);
+  return pp_check_launch("pp_conv2d");
+}
+
+template <int WC, int WP, int TC, int TP>
+static int launch_halo_any(void* stream, const ConvK& k, int Z, const HaloGeom& g);
+
 template <int WC, int WP, int TC, int TP>
 static int launch_halo_cfg(void* stream, const ConvK& k, int Z, HaloGeom g) {
   constexpr int BC = WC * TC * 16;
@@ -323,10 +622,26 @@ int launch_halo_split(void* stream, const ConvK& k, int Z) {
   if (k.Cout > 64) {
     const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
     const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
-    if (waste96 + 32 <= waste128) return launch_halo_cfg<2, 2, 3, 4>(stream, k, Z, g);  //  96 x (8 x 16)
-    return launch_halo_cfg<2, 2, 4, 4>(stream, k, Z, g);                                // 128 x (8 x 16)
+    if (waste96 + 32 <= waste128) return launch_halo_any<2, 2, 3, 4>(stream, k, Z, g);  //  96 x (8 x 16)
+    return launch_halo_any<2, 2, 4, 4>(stream, k, Z, g);                                // 128 x (8 x 16)
   }
-  return launch_halo_cfg<1, 4, 4, 2>(stream, k, Z, g);                                  //  64 x (8 x 16)
+  return launch_halo_any<1, 4, 4, 2>(stream, k, Z, g);                                  //  64 x (8 x 16)
+}
+
+// compile-time-tap kernels for the three tap shapes of RAFT (dilation 1), the runtime-tap kernel otherwise;
+// PP_CONV_HALO_CT=0 keeps the runtime-tap kernel everywhere (A/B runs, tests)
+template <int WC, int WP, int TC, int TP>
+static int launch_halo_any(void* stream, const ConvK& k, int Z, const HaloGeom& g) {
+  const char* e = getenv("PP_CONV_HALO_CT");
+  int64_t max_ldc = 0;
+  for (int sgm = 0; sgm < k.nseg; ++sgm) max_ldc = k.in_ldc[sgm] > max_ldc ? k.in_ldc[sgm] : max_ldc;
+  const bool off32 = (int64_t)k.N * k.H * k.W * max_ldc < ((int64_t)1 << 30) && (int64_t)k.Cout * k.Kp < ((int64_t)1 << 30);
+  if (!(e && e[0] == '0') && k.dh == 1 && k.dw == 1 && off32) {
+    if (k.kh == 3 && k.kw == 3) return launch_halo_ct_cfg<WC, WP, TC, TP, 3, 3>(stream, k, Z, g);
+    if (k.kh == 1 && k.kw == 5) return launch_halo_ct_cfg<WC, WP, TC, TP, 1, 5>(stream, k, Z, g);
+    if (k.kh == 5 && k.kw == 1) return launch_halo_ct_cfg<WC, WP, TC, TP, 5, 1>(stream, k, Z, g);
+  }
+  return launch_halo_cfg<WC, WP, TC, TP>(stream, k, Z, g);
 }
 
 }  // namespace pp

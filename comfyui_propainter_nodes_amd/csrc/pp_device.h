@@ -83,6 +83,10 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
 __device__ __forceinline__ void gload16_hidden(f4& dst, const void* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
 }
+// the same with a wave-uniform base in SGPRs and an unsigned 32-bit per-lane BYTE offset: no 64-bit address arithmetic
+__device__ __forceinline__ void gload16_hidden_s(f4& dst, const void* sbase, uint32_t byte_off) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(sbase) : "memory");
+}
 // counted wait for hidden loads + a scheduling barrier: no instruction (in particular no consumer of a hidden
 // load's destination) is moved across it.  The destinations are defined once and only read afterwards, so the
 // register allocator has no reason to copy them while the data is in flight (audited in the -save-temps output).
@@ -111,6 +115,7 @@ template <int N>
 inline void pp_wait_vmcnt() {}
 inline void pp_wait_lgkm0() {}
 inline void gload16_hidden(f4& dst, const void* src) { memcpy(&dst, src, 16); }
+inline void gload16_hidden_s(f4& dst, const void* sbase, uint32_t byte_off) { memcpy(&dst, static_cast<const char*>(sbase) + byte_off, 16); }
 template <int N>
 inline void wait_vmcnt_hidden() {}
 inline void pp_barrier() { pp_emu::barrier(); }
