@@ -186,6 +186,129 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
   }
 }
 
+// ---- fast epilogue.  store_quad() above decides per lane and per quad whether a tensor can be touched with a vector
+// access (alignment, partial channel quads, an activation boundary inside a quad): correct for any view, but it costs
+// ~200 executed instructions per quad with both forms of every access in the instruction stream -- for a 16-quad wave
+// tile more issue time than the MFMAs of a short reduction.  Whether EVERY quad of a launch is a full aligned vector on
+// every tensor is a property of the launch: epi_fast_ok() tests it once (scalar work), store_quad_fast() then has no
+// per-lane decisions left but the activation split.
+template <typename OT>
+__device__ __forceinline__ bool epi_fast_ok(const ConvK& p, const EpiCtx<OT>& e) {
+  constexpr uintptr_t AM = 4 * sizeof(OT) - 1;
+  bool ok = (p.Cout & 3) == 0 && (p.act_split & 3) == 0;
+  ok = ok && (p.out_ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(e.out) & AM) == 0;
+  ok = ok && (!e.bias || (reinterpret_cast<uintptr_t>(e.bias) & 15) == 0);
+  ok = ok && (!e.pre || ((p.pre_add_ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(e.pre) & AM) == 0));
+  if (p.epi != PP_EPI_NONE) {
+    ok = ok && (p.aux1_ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(e.aux1) & AM) == 0;
+    if (p.epi == PP_EPI_GRU) ok = ok && (p.aux2_ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(e.aux2) & AM) == 0;
+  }
+  return ok;
+}
+
+template <typename ET>
+__device__ __forceinline__ f4 load_quad_vec(const ET* src) {
+  if constexpr (sizeof(ET) == 2) {
+    const h4 t = *reinterpret_cast<const h4*>(src);
+    return f4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+  } else {
+    return *reinterpret_cast<const f4*>(src);
+  }
+}
+
+__device__ __forceinline__ f4 apply_act4(f4 v, int act, float param) {  // one (uniform) switch per quad
+  switch (act) {
+    case PP_ACT_RELU:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      break;
+    case PP_ACT_LEAKY:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * param;
+      break;
+    case PP_ACT_SIGMOID:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+      break;
+    case PP_ACT_TANH:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+      break;
+    case PP_ACT_GELU:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));
+      break;
+    default: break;
+  }
+  return v;
+}
+
+// the arithmetic of store_quad() (same operations in the same order) for launches that passed epi_fast_ok()
+template <typename OT>
+__device__ __forceinline__ void store_quad_fast(const ConvK& p, const EpiCtx<OT>& e, f4 v, int64_t m, int c) {
+  if (e.bias) v += *reinterpret_cast<const f4*>(e.bias + c);
+  if (e.pre) v += load_quad_vec(e.pre + m * p.pre_add_ldc + c);
+  if (p.act_split > 0 && c >= p.act_split) {  // (act_split % 4 == 0: no quad straddles the boundary)
+    v = apply_act4(v, p.act2, p.act_param);
+  } else {
+    v = apply_act4(v, p.act, p.act_param);
+    if (p.out_scale != 0.f) v *= p.out_scale;
+  }
+  if (p.epi != PP_EPI_NONE) {
+    const f4 a1 = load_quad_vec(e.aux1 + m * p.aux1_ldc + c);
+    if (p.epi == PP_EPI_MUL_AUX1) {
+      v *= a1;
+    } else if (p.epi == PP_EPI_ADD_AUX1) {
+      v += a1;
+    } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = v[r] + a1[r];
+        v[r] = s > 0.f ? s : 0.f;
+      }
+    } else if (p.epi == PP_EPI_GRU) {
+      const f4 h = load_quad_vec(e.aux2 + m * p.aux2_ldc + c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (1.f - a1[r]) * h[r] + a1[r] * v[r];
+    }
+  }
+  OT* dst = e.out + m * p.out_ldc + c;
+  if constexpr (sizeof(OT) == 2) {
+    h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<h4*>(dst) = o;
+  } else {
+    *reinterpret_cast<f4*>(dst) = v;
+  }
+}
+
+// The epilogue of a wave tile of NA x NB quads: row(b, m, ok) gives the output pixel of quad column b (and whether it
+// exists), chan(a) the first channel of quad row a for this lane, val(a, b) the finished accumulator quad (compile-time
+// indices: the callers' accumulators are register arrays).  One uniform branch picks the fast or the general form.
+template <typename OT, int NA, int NB, typename RowFn, typename ChanFn, typename ValFn>
+__device__ __forceinline__ void epilogue_quads(const ConvK& p, const EpiCtx<OT>& e, RowFn row, ChanFn chan, ValFn val) {
+  if (epi_fast_ok<OT>(p, e)) {
+    static_for<NB>([&](auto bi) {
+      int64_t m;
+      bool ok;
+      row(bi, m, ok);
+      static_for<NA>([&](auto ai) {
+        const int c = chan(ai);
+        if (ok && c < p.Cout) store_quad_fast<OT>(p, e, val(ai, bi), m, c);
+      });
+    });
+  } else {
+    static_for<NB>([&](auto bi) {
+      int64_t m;
+      bool ok;
+      row(bi, m, ok);
+      static_for<NA>([&](auto ai) {
+        const int c = chan(ai);
+        if (ok && c < p.Cout) store_quad<OT>(p, e, val(ai, bi), m, c);
+      });
+    });
+  }
+}
+
 // PP_F32X2 low term of v given its high term h = f16_rtz(v): (v - h) * 2048, saturated to the f16 range.  The
 // remainder only reaches the limit for |v| >= 32752 (ulp(h) = 32: a remainder of 31.99 scales to 65515, which would
 // round to infinity): there the representation degrades gracefully (absolute error <= 0.016 up to |v| = 65504, and
@@ -257,6 +380,8 @@ int launch_split(void* stream, const ConvK& k, int Z);
 int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // ... and its halo-tile form for stride-1 multi-tap convolutions (conv_halo.hip); returns 1 when not eligible
 int launch_halo_split(void* stream, const ConvK& k, int Z);
+// conv_halo_tall.hip: 16-row tiles, one wave per SIMD (3x3 / 1x5 / 5x1, Cout > 64); returns 1 when not eligible
+int launch_halo_tall(void* stream, const ConvK& k, int Z);
 int launch_halo_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 
 }  // namespace pp

@@ -27,12 +27,11 @@ static inline int halo_mode() {  // (read per call: a getenv is noise next to a 
 }
 
 // Geometry + eligibility shared by both forms; returns false when the flat-tile kernels should run instead.
-static inline bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* g) {
+static inline bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* g, int TH = 8) {
   const int mode = halo_mode();
   if (mode == 0) return false;
   const int ntaps = k.kh * k.kw;
   if (ntaps < 2 || k.sh != 1 || k.sw != 1 || k.pad_mode != PP_PAD_ZEROS || k.Cout <= 32) return false;
-  constexpr int TH = 8;
   g->hw = kHaloTW + (k.kw - 1) * k.dw;
   g->hrows = (TH + (k.kh - 1) * k.dh) * g->hw;
   if (g->hrows > max_rows) return false;
@@ -52,7 +51,7 @@ static inline bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* 
   g->ntiles = (int)ntiles;
   g->nct = 0;
   static const bool trace = getenv("PP_CONV_TRACE") != nullptr;  // debugging aid: which kernel family ran
-  if (trace) fprintf(stderr, "pp_conv2d: halo-tile kernel, %dx%d taps, Cout %d, %d tiles\n", k.kh, k.kw, k.Cout, g->ntiles);
+  if (trace) fprintf(stderr, "pp_conv2d: halo-tile kernel (%d-row tiles), %dx%d taps, Cout %d, %d tiles\n", TH, k.kh, k.kw, k.Cout, g->ntiles);
   return true;
 }
 

@@ -182,17 +182,15 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_halo_f16_kernel(const ConvK
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
   const int ox = tx0 + frow;
-  static_for<TP>([&](auto bi) {
-    constexpr int b = decltype(bi)::value;
-    const int oy = ty0 + wp * TP + b;
-    const int64_t m = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
-    const bool inside = oy < p.Ho && ox < p.Wo;
-    static_for<TC>([&](auto ai) {
-      constexpr int a = decltype(ai)::value;
-      const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
-      if (inside && c < p.Cout) store_quad<OT>(p, e, acc[a][b], m, c);
-    });
-  });
+  epilogue_quads<OT, TC, TP>(
+      p, e,
+      [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
+        const int oy = ty0 + wp * TP + decltype(bi)::value;
+        m = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
+        ok = oy < p.Ho && ox < p.Wo;
+      },
+      [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
+      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
 }
 
 template <typename OT, int WC, int WP, int TC, int TP, int XPASS>

@@ -406,29 +406,29 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(const ConvK p)
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
   if constexpr (M32) {
-    static_for<TP2>([&](auto bi) {
-      constexpr int b = decltype(bi)::value;
-      const int64_t m = p_base + wp * TP * 16 + b * 32 + r32;
-      static_for<TC2>([&](auto ai) {
-        constexpr int a = decltype(ai)::value;
-        static_for<4>([&](auto qi) {
-          constexpr int q = decltype(qi)::value;
-          const int c = c_base + wc * TC * 16 + a * 32 + 8 * q + 4 * kh32;
-          const f4 v = {acc32[a][b][4 * q], acc32[a][b][4 * q + 1], acc32[a][b][4 * q + 2], acc32[a][b][4 * q + 3]};
-          if (m < p.M && c < p.Cout) store_quad<OT>(p, e, v, m, c);
+    epilogue_quads<OT, TC2 * 4, TP2>(
+        p, e,
+        [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
+          m = p_base + wp * TP * 16 + decltype(bi)::value * 32 + r32;
+          ok = m < p.M;
+        },
+        [&](auto ai) PP_INLINE_LAMBDA {
+          constexpr int a = decltype(ai)::value / 4, q = decltype(ai)::value % 4;
+          return c_base + wc * TC * 16 + a * 32 + 8 * q + 4 * kh32;
+        },
+        [&](auto ai, auto bi) PP_INLINE_LAMBDA {
+          constexpr int a = decltype(ai)::value / 4, q = decltype(ai)::value % 4, b = decltype(bi)::value;
+          return f4{acc32[a][b][4 * q], acc32[a][b][4 * q + 1], acc32[a][b][4 * q + 2], acc32[a][b][4 * q + 3]};
         });
-      });
-    });
   } else {
-    static_for<TP>([&](auto bi) {
-      constexpr int b = decltype(bi)::value;
-      const int64_t m = p_base + wp * TP * 16 + b * 16 + frow;
-      static_for<TC>([&](auto ai) {
-        constexpr int a = decltype(ai)::value;
-        const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
-        if (m < p.M && c < p.Cout) store_quad<OT>(p, e, acc[a][b], m, c);
-      });
-    });
+    epilogue_quads<OT, TC, TP>(
+        p, e,
+        [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
+          m = p_base + wp * TP * 16 + decltype(bi)::value * 16 + frow;
+          ok = m < p.M;
+        },
+        [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
+        [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
   }
 }
 

@@ -213,15 +213,14 @@ __global__ void __launch_bounds__(kKS * 256) conv_ksplit_kernel(const ConvK p) {
   e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
-  static_for<TP>([&](auto bi) {
-    constexpr int b = decltype(bi)::value;
-    const int64_t m = p_base + b * 16 + frow;
-    static_for<TC>([&](auto ai) {
-      constexpr int a = decltype(ai)::value;
-      const int c = c_base + wave * TC * 16 + a * 16 + fgrp * 4;
-      if (m < p.M && c < p.Cout) store_quad<OT>(p, e, acc[a][b], m, c);
-    });
-  });
+  epilogue_quads<OT, TC, TP>(
+      p, e,
+      [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
+        m = p_base + decltype(bi)::value * 16 + frow;
+        ok = m < p.M;
+      },
+      [&](auto ai) PP_INLINE_LAMBDA { return c_base + wave * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
+      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
 }
 
 template <typename OT>

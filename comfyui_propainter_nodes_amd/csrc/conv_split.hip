@@ -282,16 +282,16 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
   e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
-  static_for<TP>([&](auto bi) {
-    constexpr int b = decltype(bi)::value;
-    const int64_t m = p_base + wp * TP * 16 + b * 16 + frow;
-    static_for<TC>([&](auto ai) {
-      constexpr int a = decltype(ai)::value;
-      const int c = c_base + wc * TC * 16 + a * 16 + fgrp * 4;
-      const f4 v = acc[a][b] + accx[a][b] * LINV;
-      if (m < p.M && c < p.Cout) store_quad<OT>(p, e, v, m, c);
-    });
-  });
+  epilogue_quads<OT, TC, TP>(
+      p, e,
+      [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
+        m = p_base + wp * TP * 16 + decltype(bi)::value * 16 + frow;
+        ok = m < p.M;
+      },
+      [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
+      [&](auto ai, auto bi) PP_INLINE_LAMBDA {
+        return acc[decltype(ai)::value][decltype(bi)::value] + accx[decltype(ai)::value][decltype(bi)::value] * LINV;
+      });
 }
 
 template <typename OT, int WC, int WP, int TC, int TP>
@@ -316,7 +316,9 @@ struct SplitFamily {
 };
 
 int launch_split(void* stream, const ConvK& k, int Z) {
-  const int rc = launch_halo_split(stream, k, Z);  // stride-1 multi-tap convolutions: pixel tile + halo staged once per chunk
+  int rc = launch_halo_tall(stream, k, Z);         // large 3x3 / 1x5 / 5x1 problems: 16-row tiles, one wave per SIMD
+  if (rc != 1) return rc;
+  rc = launch_halo_split(stream, k, Z);            // stride-1 multi-tap convolutions: pixel tile + halo staged once per chunk
   if (rc != 1) return rc;
   return launch_by_cout<SplitFamily<float>>(stream, k, Z);
 }

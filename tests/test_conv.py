@@ -44,6 +44,11 @@ CASES = [
     ("f32x2", 1, 21, 18, [64, 4], 64, (5, 1), 1, (2, 0), 1, 1, "tanh"),
     ("f32x2", 1, 10, 40, [32], 126, (2, 3), 1, (1, 0), 1, 2, None),
     ("f32x2", 1, 16, 32, [8], 40, 3, 1, 0, 1, 1, "leaky"),
+    # 16-row halo tiles, one wave per SIMD (PP_CONV_HALO_TALL=force): 128- and 96-channel tiles, 3x3 / 1x5 / 5x1, several
+    # chunks and segments (the double-buffered pixel tile and the 2-stage weight ring wrap), partial row / column tiles
+    ("f32x2", 1, 35, 20, [72], 128, 3, 1, 1, 1, 1, "tanh"),
+    ("f32x2", 2, 18, 17, [32, 32], 256, (1, 5), 1, (0, 2), 1, 1, "sigmoid"),
+    ("f32x2", 1, 20, 16, [36, 4], 100, (5, 1), 1, (2, 0), 1, 1, None),
     # f16 halo-tile kernel: several tiles, segments with a partial chunk, dilation 2 (the 5-pass pixel stage), 96 / 64 tiles
     (torch.float16, 2, 19, 37, [40, 24], 130, 3, 1, 1, 1, 1, "relu"),
     (torch.float16, 1, 17, 33, [32], 192, 3, 1, 2, 2, 1, "leaky"),
@@ -69,12 +74,14 @@ def _ref_input(x, segC, groups):
 
 
 # ("xlforce" = the experimental 8-wave 256-channel tiles: emulator only until they have been measured on the MI355X)
-@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"), ("emu", "ksplit"),
+@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"), ("emu", "tall"),
+                                     ("emu", "ksplit"),
                                      pytest.param("hip", "large", marks=pytest.mark.gpu),
                                      pytest.param("hip", "small", marks=pytest.mark.gpu),
                                      pytest.param("hip", "xlforce", marks=pytest.mark.gpu),
                                      pytest.param("hip", "tiny", marks=pytest.mark.gpu),
                                      pytest.param("hip", "halo", marks=pytest.mark.gpu),
+                                     pytest.param("hip", "tall", marks=pytest.mark.gpu),
                                      pytest.param("hip", "ksplit", marks=pytest.mark.gpu)])
 def test_conv2d_matches_torch(be, tile):
     """Every case on both tile families (128-pixel tiles / 32-pixel tiles for small problems).  The tile
@@ -92,6 +99,9 @@ def test_conv2d_matches_torch(be, tile):
     env = dict(os.environ, PP_CONV_TILE=tile, PP_TEST_BACKEND=be, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     env["PP_CONV_HALO"] = "0"      # the flat-tile kernels ...
     env["PP_CONV_KSPLIT"] = "0"
+    env["PP_CONV_HALO_TALL"] = "0"
+    if tile == "tall":             # ... 16-row halo tiles wherever they apply (3x3 / 1x5 / 5x1, Cout > 64), 8-row ones elsewhere
+        env.update(PP_CONV_TILE="large", PP_CONV_HALO="force", PP_CONV_HALO_TALL="force")
     if tile == "halo":             # ... or the halo-tile kernel for every eligible PP_F32X2 geometry, whatever its size
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
     if tile == "ksplit":           # ... or the in-work-group split-K kernel for every f16 problem with >= 4 chunks

@@ -99,7 +99,7 @@ def audit_function(name, lines):
 def main(path):
     s = open(path).read()
     total = 0
-    for m in re.finditer(r"^(_ZN2pp\w*conv_(?:halo_)?split(?:_ct)?_kernel\w+):", s, flags=re.M):
+    for m in re.finditer(r"^(_ZN2pp\w*conv_(?:halo_)?split(?:_ct|_tall)?_kernel\w+):", s, flags=re.M):
         a = m.end()
         b = s.index(".Lfunc_end", a)
         bad = audit_function(m.group(1), s[a:b].split("\n"))

@@ -37,6 +37,8 @@ struct Shape {
 
 static const std::vector<Shape> SHAPES = {
     {"raft_gru_1x5_f32x2", PP_F32X2, 158, 45, 80, {128, 128}, 256, 1, 5, 0, 2},
+    {"raft_gru128_1x5_f32x2", PP_F32X2, 158, 45, 80, {128, 128}, 128, 1, 5, 0, 2},
+    {"raft_gru128_5x1_f32x2", PP_F32X2, 158, 45, 80, {128, 128}, 128, 5, 1, 2, 0},
     {"raft_gru_1x5_f32", PP_F32, 158, 45, 80, {128, 128}, 256, 1, 5, 0, 2},
     {"raft_convc2_f32x2", PP_F32X2, 158, 45, 80, {256}, 192, 3, 3, 1, 1},
     {"raft_fh1_f32x2", PP_F32X2, 158, 45, 80, {128}, 256, 3, 3, 1, 1},
