@@ -69,17 +69,34 @@ def _compile_all(objs_dir: Path, compile_one, link, out: Path, stamp_extra: str,
     return out
 
 
+# translation units with hidden (inline-asm) loads: their gfx950 ISA is kept next to the object so that
+# tests/test_isa_audit.py audits the code that ships instead of compiling a second copy
+ISA_KEPT = ("conv_split", "conv_halo", "conv_halo_tall")
+
+
+def isa_path(stem: str) -> Path:
+    return PKG / "build" / "hip" / f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s"
+
+
 def build_hip(force: bool = False) -> Path:
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=off",
              "-I", str(CSRC), "-I", str(ROOT / "include")]
 
     def compile_one(src: Path, obj: Path) -> None:
-        _run([HIPCC, *flags, "-c", str(src), "-o", str(obj)])
+        if src.stem in ISA_KEPT:
+            _run([HIPCC, *flags, "-save-temps=obj", "-c", str(src), "-o", str(obj)])
+            for tmp in obj.parent.glob(src.stem + "-*"):       # keep the device ISA, drop the bulky intermediates
+                if tmp != isa_path(src.stem):
+                    tmp.unlink()
+            for tmp in obj.parent.glob(src.name + "-*"):
+                tmp.unlink()
+        else:
+            _run([HIPCC, *flags, "-c", str(src), "-o", str(obj)])
 
     def link(objs: list[Path], out: Path) -> None:
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(out)])
 
-    return _compile_all(PKG / "build" / "hip", compile_one, link, LIB, "hip" + " ".join(flags), force)
+    return _compile_all(PKG / "build" / "hip", compile_one, link, LIB, "hip-isa1 " + " ".join(flags), force)
 
 
 def main(argv: list[str]) -> int:

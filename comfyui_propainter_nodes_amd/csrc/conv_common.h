@@ -317,6 +317,24 @@ __device__ __forceinline__ float split_lo(float v, float h) {
   const float r = (v - h) * 2048.f;
   return fminf(fmaxf(r, -65504.f), 65504.f);
 }
+// The split of two values as the kernels' pixel staging does it, 4 vector-ALU operations per value: h = f16_rtz(v)
+// (packed convert), t = v - h (exact; one fma with the f16 operand converted in the instruction), t clamped to +-32
+// (only bites for |v| >= 65536, where it makes the representation saturate), l = f16_rtz(2048 t) (packed convert:
+// round-toward-zero never overflows to infinity, so the scaled remainder needs no second clamp; split_lo() above
+// with a round-to-nearest convert took 7).  l's rounding differs from the host-side weight split by at most one f16
+// ulp of a term that is itself 2^-11 of v.
+__device__ __forceinline__ void split_pair(float c0, float c1, h2& hh, h2& ll) {
+  hh = cvt_pkrtz_f16(c0, c1);
+  float t0 = __builtin_fmaf((float)hh[0], -1.f, c0), t1 = __builtin_fmaf((float)hh[1], -1.f, c1);
+#ifdef PP_EMU
+  t0 = fminf(fmaxf(t0, -32.f), 32.f);
+  t1 = fminf(fmaxf(t1, -32.f), 32.f);
+#else
+  t0 = __builtin_amdgcn_fmed3f(t0, -32.f, 32.f);
+  t1 = __builtin_amdgcn_fmed3f(t1, -32.f, 32.f);
+#endif
+  ll = cvt_pkrtz_f16(t0 * 2048.f, t1 * 2048.f);
+}
 
 // one 16-byte f16 MFMA fragment from LDS (PP_ABLATE & 16: a register constant instead)
 __device__ __forceinline__ h8 lds_frag(const void* ptr) {
@@ -383,5 +401,7 @@ int launch_halo_split(void* stream, const ConvK& k, int Z);
 // conv_halo_tall.hip: 16-row tiles, one wave per SIMD (3x3 / 1x5 / 5x1, Cout > 64); returns 1 when not eligible
 int launch_halo_tall(void* stream, const ConvK& k, int Z);
 int launch_halo_f16(void* stream, const ConvK& k, int Z, bool out_f16);
+// conv_direct.hip: at most 4 output channels, streaming fp32-FMA kernel; returns 1 when not eligible
+int launch_direct_small_cout(void* stream, const ConvK& k, int Z, int dtype, bool out_f16);
 
 }  // namespace pp

@@ -165,11 +165,12 @@ __global__ void __launch_bounds__(256, 1) conv_halo_split_tall_kernel(const Conv
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
-        const h2 hh = cvt_pkrtz_f16(c0, c1);
+        h2 hh, ll;
+        split_pair(c0, c1, hh, ll);
         h[e] = hh[0];
         h[e + 1] = hh[1];
-        l[e] = (half_t)split_lo(c0, (float)hh[0]);
-        l[e + 1] = (half_t)split_lo(c1, (float)hh[1]);
+        l[e] = ll[0];
+        l[e + 1] = ll[1];
       }
       unsigned char* rowp = xt + (xrow0 + i * XROWS) * XP + xj * 16;
       *reinterpret_cast<h8*>(rowp) = h;

@@ -515,6 +515,10 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   k.pre_add = p->pre_add; k.pre_add_ldc = (int)p->pre_add_ldc;
   if (p->pre_add && p->Z != 1) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: pre_add with Z > 1");
   const int Z = (int)p->Z;
+  if (k.Cout <= 4) {  // 2-3 output channels on a 32-channel MFMA tile are wasted matrix work: streaming vector-ALU kernel
+    const int rd = launch_direct_small_cout(stream, k, Z, p->dtype, p->out_dtype == PP_F16);
+    if (rd != 1) return rd;
+  }
   if (p->dtype == PP_F16) {
     const int rc = launch_ksplit_f16(stream, k, Z, p->out_dtype == PP_F16);  // small M, long K: in-work-group split K
     if (rc != 1) return rc;

@@ -183,11 +183,12 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
       for (int e = 0; e < 8; e += 2) {
         const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
         if constexpr (!(PP_ABLATE & 8)) {
-          const h2 hh = cvt_pkrtz_f16(c0, c1);
+          h2 hh, ll;
+          split_pair(c0, c1, hh, ll);
           h[e] = hh[0];
           h[e + 1] = hh[1];
-          l[e] = (half_t)split_lo(c0, (float)hh[0]);
-          l[e + 1] = (half_t)split_lo(c1, (float)hh[1]);
+          l[e] = ll[0];
+          l[e + 1] = ll[1];
         } else {  // no arithmetic: the raw bit patterns
           const h2 r0 = __builtin_bit_cast(h2, c0), r1 = __builtin_bit_cast(h2, c1);
           h[e] = r0[0];

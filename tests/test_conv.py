@@ -390,3 +390,85 @@ if __name__ == "__main__":  # child process of test_conv2d_matches_torch
             print("FAILED CASE", case, flush=True)
             raise
         print("case", i, "ok", flush=True)
+
+
+def test_direct_small_cout_kernel(backend, monkeypatch):
+    """conv_direct.hip (at most 4 output channels, fp32 FMAs on the vector ALU) against float64 torch: the three layers it
+    exists for (RAFT flow head 256 -> 2 with the in-place `coords += delta` epilogue, generator output 64 -> 3 tanh into a
+    channel view, flow-completion output 32 -> 2) at sizes with partial 16 x 16 tiles and a partial 32-channel chunk, every
+    weight packing (PP_F32X2 / f32 / f16), both output types, then seeded random epilogues."""
+    import random
+
+    monkeypatch.setenv("PP_CONV_DIRECT", "force")
+    dev = backend
+    g = torch.Generator().manual_seed(31)
+    acts = {None: lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+
+    # RAFT flow head: f32 tensors, PP_F32X2 and exact packings, delta added onto the flow in place
+    for split in (True, False):
+        x = torch.randn(2, 19, 37, 256, generator=g)
+        w = torch.randn(2, 256, 3, 3, generator=g) * 0.05
+        b = torch.randn(2, generator=g)
+        spec = ops.make_conv_spec(w, b, torch.float32, padding=1, split=split).to(dev)
+        flow0 = torch.randn(2, 19, 37, 2, generator=g)
+        flow = flow0.clone().to(dev)
+        ops.conv2d(spec, [x.to(dev)], flow, epi="add", aux1=flow)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + flow0.double()
+        assert (flow.double().cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+    # f16 layers: 64 -> 3 tanh into [..., 0:3] of a 4-channel buffer; 40 -> 2 (partial chunk), f16 and f32 outputs; 1x3 taps
+    for cin, cout, k, pad, act, odt in ((64, 3, (3, 3), (1, 1), "tanh", torch.float16), (40, 2, (3, 3), (1, 1), None, torch.float16),
+                                        (40, 2, (3, 3), (1, 1), "leaky", torch.float32), (32, 4, (1, 3), (0, 1), "relu", torch.float16)):
+        x = torch.randn(1, 21, 34, cin, generator=g).half()
+        w = torch.randn(cout, cin, *k, generator=g) * 0.1
+        b = torch.randn(cout, generator=g)
+        spec = ops.make_conv_spec(w, b, torch.float16, padding=pad).to(dev)
+        buf = torch.full((1, 21, 34, 4), 9.0, dtype=odt, device=dev)
+        ops.conv2d(spec, [x.to(dev)], buf[..., 0:cout], act=act, act_param=0.2)
+        ref = acts[act](F.conv2d(x.double().permute(0, 3, 1, 2), w.half().double(), b.double(), padding=pad)).permute(0, 2, 3, 1)
+        tol = (4e-3 if odt == torch.float16 else 2e-5) * max(1.0, ref.abs().max().item())
+        assert (buf[..., 0:cout].double().cpu() - ref).abs().max().item() <= tol, (cin, cout, act, odt)
+        assert torch.all(buf[..., cout:].float().cpu() == 9.0)
+
+    # random epilogues on the direct path
+    rnd = random.Random(77)
+    for _ in range(10):
+        cout = rnd.randint(1, 4)
+        cin = 4 * rnd.randint(1, 12)
+        H, W = rnd.randint(5, 20), rnd.randint(5, 20)
+        x = torch.randn(1, H, W, cin, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+        b = torch.randn(cout, generator=g) if rnd.random() < 0.8 else None
+        spec = ops.make_conv_spec(w, b, torch.float32, padding=1, split=rnd.random() < 0.5).to(dev)
+        ext = rnd.choice([0, 1, 4])
+        obuf = torch.full((1, H, W, cout + ext), 3.0, device=dev)
+        act = rnd.choice(list(acts))
+        act2, asplit = (rnd.choice(["sigmoid", "relu"]), rnd.randint(1, cout - 1)) if cout > 1 and rnd.random() < 0.4 else (None, 0)
+        scale = rnd.choice([0.0, 5.0, 0.25])
+        epi = rnd.choice([None, "mul", "add", "add_relu", "gru"])
+        a1 = torch.rand(1, H, W, cout, generator=g) if epi else None
+        a2 = torch.randn(1, H, W, cout, generator=g) if epi == "gru" else None
+        pre = torch.randn(1, H, W, cout, generator=g) if rnd.random() < 0.4 else None
+        ops.conv2d(spec, [x.to(dev)], obuf[..., :cout], act=act, act_param=0.2, act2=act2, act_split=asplit, out_scale=scale, epi=epi,
+                   aux1=None if a1 is None else a1.to(dev), aux2=None if a2 is None else a2.to(dev),
+                   pre_add=None if pre is None else pre.to(dev))
+        v = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None if b is None else b.double(), padding=1).permute(0, 2, 3, 1)
+        if pre is not None:
+            v = v + pre.double()
+        if asplit > 0:
+            lo = acts[act](v[..., :asplit])
+            v = torch.cat([lo * scale if scale != 0.0 else lo, acts[act2](v[..., asplit:])], -1)
+        else:
+            v = acts[act](v)
+            v = v * scale if scale != 0.0 else v
+        if epi == "mul":
+            v = v * a1.double()
+        elif epi == "add":
+            v = v + a1.double()
+        elif epi == "add_relu":
+            v = F.relu(v + a1.double())
+        elif epi == "gru":
+            v = (1 - a1.double()) * a2.double() + a1.double() * v
+        cfg = (cin, cout, act, act2, asplit, scale, epi, ext, pre is not None)
+        assert (obuf[..., :cout].double().cpu() - v).abs().max().item() <= 3e-5 * max(1.0, v.abs().max().item()), cfg
+        assert torch.all(obuf[..., cout:].cpu() == 3.0), cfg

@@ -42,6 +42,9 @@ static const std::vector<Shape> SHAPES = {
     {"raft_gru_1x5_f32", PP_F32, 158, 45, 80, {128, 128}, 256, 1, 5, 0, 2},
     {"raft_convc2_f32x2", PP_F32X2, 158, 45, 80, {256}, 192, 3, 3, 1, 1},
     {"raft_fh1_f32x2", PP_F32X2, 158, 45, 80, {128}, 256, 3, 3, 1, 1},
+    {"raft_fh2_f32x2", PP_F32X2, 158, 45, 80, {256}, 2, 3, 3, 1, 1},
+    {"dec6_f16", PP_F16, 14, 360, 640, {64}, 3, 3, 3, 1, 1},
+    {"rfc_up2_f16", PP_F16, 158, 360, 640, {32}, 2, 3, 3, 1, 1},
     {"enc_3x3_256_384_f16", PP_F16, 16, 90, 160, {256}, 384, 3, 3, 1, 1},
     {"f16_3x3_256_512", PP_F16, 16, 90, 160, {256}, 512, 3, 3, 1, 1},
     {"dcn_offset_f16", PP_F16, 16, 90, 160, {128, 128, 8}, 128, 3, 3, 1, 1},
