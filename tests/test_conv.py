@@ -53,6 +53,9 @@ CASES = [
     (torch.float16, 2, 19, 37, [40, 24], 130, 3, 1, 1, 1, 1, "relu"),
     (torch.float16, 1, 17, 33, [32], 192, 3, 1, 2, 2, 1, "leaky"),
     (torch.float16, 1, 12, 20, [64, 8], 64, (3, 1), 1, (2, 0), (2, 1), 1, None),
+    # ... its compile-time 3x3 form (rows of three taps per weight stage): 128- and 64-channel tiles, several chunks / segments
+    (torch.float16, 1, 19, 21, [72], 128, 3, 1, 1, 1, 1, "leaky"),
+    (torch.float16, 2, 9, 33, [32, 40], 64, 3, 1, 1, 1, 1, None),
     # in-work-group split-K kernel (PP_CONV_KSPLIT=force): reductions of 9 / 27 / 45 / 10 chunks over 4 groups, segments,
     # a last group with fewer (or no) chunks, partial 32-pixel and 128-channel tiles
     (torch.float16, 1, 7, 9, [32], 128, 3, 1, 1, 1, 1, "leaky"),
@@ -74,13 +77,14 @@ def _ref_input(x, segC, groups):
 
 
 # ("xlforce" = the experimental 8-wave 256-channel tiles: emulator only until they have been measured on the MI355X)
-@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"), ("emu", "tall"),
+@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"), ("emu", "halo_rt"), ("emu", "tall"),
                                      ("emu", "ksplit"),
                                      pytest.param("hip", "large", marks=pytest.mark.gpu),
                                      pytest.param("hip", "small", marks=pytest.mark.gpu),
                                      pytest.param("hip", "xlforce", marks=pytest.mark.gpu),
                                      pytest.param("hip", "tiny", marks=pytest.mark.gpu),
                                      pytest.param("hip", "halo", marks=pytest.mark.gpu),
+                                     pytest.param("hip", "halo_rt", marks=pytest.mark.gpu),
                                      pytest.param("hip", "tall", marks=pytest.mark.gpu),
                                      pytest.param("hip", "ksplit", marks=pytest.mark.gpu)])
 def test_conv2d_matches_torch(be, tile):
@@ -104,6 +108,8 @@ def test_conv2d_matches_torch(be, tile):
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force", PP_CONV_HALO_TALL="force")
     if tile == "halo":             # ... or the halo-tile kernel for every eligible PP_F32X2 geometry, whatever its size
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
+    if tile == "halo_rt":          # ... with the runtime-tap kernels also where a compile-time-tap form exists
+        env.update(PP_CONV_TILE="large", PP_CONV_HALO="force", PP_CONV_HALO_CT="0")
     if tile == "ksplit":           # ... or the in-work-group split-K kernel for every f16 problem with >= 4 chunks
         env.update(PP_CONV_TILE="large", PP_CONV_KSPLIT="force")
     r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
