@@ -102,12 +102,74 @@ def _expand_masks(m: torch.Tensor, T: int) -> torch.Tensor:
 def _output(comp_u8: torch.Tensor, fm_u8: torch.Tensor, md_u8: torch.Tensor):
     """handle_output (image_utils.py:276-290): IMAGE fp32 k/255 on the host, the two masks fp32 on the device.
     The uint8 frames cross PCIe (a quarter of the fp32 bytes) and become float32(k) / 255 on the host cores (the same
-    IEEE division as the reference's numpy expression); PP_OUTPUT=device converts on the GPU and copies fp32 instead."""
+    IEEE division as the reference's numpy expression); PP_OUTPUT=device converts on the GPU and copies fp32 instead.
+    (Default on a GPU: PP_OUTPUT=stream, the same host arithmetic streamed under the window loop by _HostImageSink;
+    PP_OUTPUT=host selects this function's blocking form.)"""
     if os.environ.get("PP_OUTPUT") == "device":
         images = ops.image_from_u8(comp_u8).cpu()
     else:
         images = comp_u8.cpu().to(torch.float32).div_(255.0)
     return images, fm_u8.float().squeeze(), md_u8.float().squeeze()
+
+
+class _HostImageSink:
+    """Streams the composed uint8 frames to the host while the remaining windows run: pipeline.run_inpainting reports every
+    frame range that has received its last blend; the range is copied on a side stream into pinned memory and a worker
+    thread turns it into the fp32 IMAGE rows (float32(k) / 255, the reference's expression) -- the D2H copy and the host
+    conversion of an 80-frame 640x360 clip (16 ms after the last kernel) hide behind the window loop."""
+
+    def __init__(self, T: int, H: int, W: int, device):
+        import queue
+        import threading
+
+        self.device = device
+        key = (T, H, W)
+        if key not in _HostImageSink._pinned:      # page-locking 55 MB costs more than the copy: keep the buffer
+            _HostImageSink._pinned.clear()
+            _HostImageSink._pinned[key] = torch.empty(T, H, W, 3, dtype=torch.uint8).pin_memory()
+        self.pinned = _HostImageSink._pinned[key]
+        self.image = torch.empty(T, H, W, 3, dtype=torch.float32)
+        self.stream = torch.cuda.Stream(device)
+        self.q: "queue.Queue" = queue.Queue()
+        self.error: BaseException | None = None
+        self.worker = threading.Thread(target=self._convert, daemon=True)
+        self.worker.start()
+
+    _pinned: dict = {}
+
+    def frames_final(self, comp: torch.Tensor, lo: int, hi: int) -> None:
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            self.pinned[lo:hi].copy_(comp[lo:hi], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.stream)
+        self.q.put((lo, hi, copied))
+
+    def _convert(self) -> None:
+        try:
+            # first touch of the IMAGE's pages (221 MB for 80 frames of 640x360) while the GPU is still in RAFT: page
+            # faults, not arithmetic, are most of the host-side output cost
+            self.image.zero_()
+            while True:
+                item = self.q.get()
+                if item is None:
+                    return
+                lo, hi, copied = item
+                copied.synchronize()
+                dst = self.image[lo:hi]
+                dst.copy_(self.pinned[lo:hi])              # uint8 -> float32(k), exact
+                dst.div_(255.0)                            # / 255: the reference's IEEE division
+        except BaseException as e:  # surfaced by finish()
+            self.error = e
+
+    def finish(self) -> torch.Tensor:
+        self.q.put(None)
+        self.worker.join()
+        if self.error is not None:
+            raise self.error
+        return self.image
 
 
 TRACE: dict | None = None  # debugging / test aid: when a dict, the next node call leaves its stage tensors in it
@@ -116,9 +178,14 @@ TRACE: dict | None = None  # debugging / test aid: when a dict, the next node ca
 def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer):
     if TRACE is not None:
         TRACE.update(frames_u8=fr_u8, flow_masks=fm, masks_dilated=md)
-    comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32)
+    stream_out = fr_u8.is_cuda and os.environ.get("PP_OUTPUT", "stream") == "stream" and TRACE is None
+    sink = _HostImageSink(*fr_u8.shape[:3], fr_u8.device) if stream_out else None
+    comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32, sink=sink)
     tm.mark("pipeline")
-    out = _output(comp, fm, md)
+    if sink is not None:
+        out = (sink.finish(), fm.float().squeeze(), md.float().squeeze())
+    else:
+        out = _output(comp, fm, md)
     tm.mark("output(u8->float, D2H)")
     tm.done()
     return out

@@ -194,10 +194,15 @@ def device_schedule(config: ProPainterConfig):
 
 
 def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, config: ProPainterConfig,
-                   trace: dict | None = None, to_host: bool = True, frames_f32: torch.Tensor | None = None) -> torch.Tensor:
+                   trace: dict | None = None, to_host: bool = True, frames_f32: torch.Tensor | None = None,
+                   sink=None) -> torch.Tensor:
     """uint8 arrays / tensors in ([T,H,W,3], [T,H,W], [T,H,W]) -> composed uint8 frames [T,H,W,3]
     (CPU tensor, or left in HBM when `to_host` is False).  `frames_f32` = the fp32 [-1,1] frames when the caller
     already produced them on the device (ops.frames_from_image).
+
+    `sink` (optional): an object with `frames_final(comp, lo, hi)`, called as soon as frames [lo, hi) of the composed clip
+    can no longer change (no later window has them as local frames) -- the node streams them to the host under the
+    remaining windows (nodes._HostImageSink).
 
     = process_inpainting (:314-341) + feature_propagation (:228-311) of the reference."""
     dev = config.device
@@ -234,12 +239,20 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     schedule, spans, table = device_schedule(config)
     props = gen.propagate_windows(st, [nb for nb, _ in schedule])
     mark("feature_propagation(all windows batched)")
+    done = 0  # frames [0, done) are final
     for wi, (nb, refs) in enumerate(schedule):
         out = gen.forward_window(st, nb, refs, local_prop=props[wi])
         a, b = spans[wi]
         ops.compose_u8(out, table[0, a:b], table[1, a:b], md, fr_u8, comp)
         if trace is not None:
             trace["pred_imgs"].append(out[..., :3].float().cpu())
+        if sink is not None:
+            # the windows slide forward (pipeline.window_schedule): everything before the next window's first local frame
+            # has received its last blend
+            nxt = min(schedule[wi + 1][0]) if wi + 1 < len(schedule) else T
+            if nxt > done:
+                sink.frames_final(comp, done, nxt)
+                done = nxt
     mark("windows(transformer+decoder+compose)")
     if timing:
         print("[pp] stage ms: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f}" for a, b in zip(marks, marks[1:])), flush=True)

@@ -50,6 +50,24 @@ def test_inpaint_node_with_resize_matches_oracle(seeded_models):
 
 
 @pytest.mark.gpu
+def test_streamed_output_equals_blocking_output(seeded_models, monkeypatch):
+    """The node streams finished frame ranges to the host under the remaining windows (nodes._HostImageSink): same IMAGE,
+    bit for bit, as the blocking copy + conversion after the last kernel, also when the clip spans several windows and the
+    pinned staging buffer is reused by a second call."""
+    T = 13
+    image, mask = synth.synthetic_clip(T, 128, 144)
+    node = nodes.ProPainterInpaint()
+    kw = dict(image=image, mask=mask, width=144, height=128, mask_dilates=3, flow_mask_dilates=4, fp16="enable", raft_iter=2,
+              neighbor_length=4, ref_stride=3, subvideo_length=80)
+    outs = {}
+    for mode in ("host", "stream", "stream"):
+        monkeypatch.setenv("PP_OUTPUT", mode)
+        outs.setdefault(mode, []).append(getattr(node, node.FUNCTION)(**kw)[0].clone())
+    assert outs["host"][0].dtype == torch.float32 and not outs["stream"][0].is_cuda
+    assert torch.equal(outs["host"][0], outs["stream"][0]) and torch.equal(outs["host"][0], outs["stream"][1])
+
+
+@pytest.mark.gpu
 def test_outpaint_node_matches_oracle(seeded_models):
     T = 4
     image, _ = synth.synthetic_clip(T, 128, 128)

@@ -26,7 +26,7 @@ def test_im2col_matches_unfold(backend):
     assert torch.equal(out2.cpu()[..., :75], ref2)
 
 
-@pytest.mark.parametrize("C", [64, 96, 128])
+@pytest.mark.parametrize("C", [64, 96, 128, 256, 30])  # (30: not a multiple of 4 -> the scalar form of the kernels)
 def test_instnorm(backend, C):
     dev = backend
     g = torch.Generator().manual_seed(2)
