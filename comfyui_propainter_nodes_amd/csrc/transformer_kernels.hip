@@ -175,56 +175,62 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const AttnK<T> k)
   const int dbase = (tid & 7) * 16;  // 16 head-dim values
   const int vblk = ((kr >> 2) ^ (tid & 7)) * 4 + (kr & 3);  // swizzled key slot of this thread's V^T stores ((d>>4)&7 == tid&7)
 
+  // K / V of a 32-key tile travel global -> registers -> LDS; the loads of tile kt+32 are issued right after the barrier
+  // that publishes tile kt, so their latency hides behind the 32 MFMAs and the softmax of tile kt (r02: the loop used to
+  // load, store and only then compute; 267 -> 256 us.  Also measured and NOT kept: skipping the O rescale when no running
+  // maximum moved (wave-uniform branch) together with a per-window LDS table of the key offsets: 272 us).
+  h8 kv0, kv1, vv0, vv1;
+  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+    const int kid = kt + kr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kv0[e] = kv1[e] = vv0[e] = vv1[e] = (half_t)0.f;
+    if (kid < nk) {
+      const T *kp, *vp;
+      int fr, r;
+      if (masked) {
+        const int fi = kid / per_frame;
+        r = kid - fi * per_frame;
+        fr = k.t_ind[fi];
+      } else {
+        fr = frame;
+        r = kid;
+      }
+      if (r < kWinTok + 148) {
+        int y, x;
+        if (r < kWinTok) {
+          y = r0 + r / kWinW;
+          x = c0 + r % kWinW;
+        } else {
+          const int ni = r - kWinTok;
+          y = (r0 + (int)k.nb[2 * ni] + k.Hp) % k.Hp;
+          x = (c0 + (int)k.nb[2 * ni + 1] + k.Wp) % k.Wp;
+        }
+        const T* tokp = k.qkv + ((int64_t)(fr * k.Hp + y) * k.Wp + x) * (3 * kDim) + head * kHeadDim;
+        kp = tokp + kDim;
+        vp = tokp + 2 * kDim;
+      } else {
+        const T* tokp = k.pkv + ((int64_t)fr * k.npool + (r - kWinTok - 148)) * (2 * kDim) + head * kHeadDim;
+        kp = tokp;
+        vp = tokp + kDim;
+      }
+      kv0 = ld8h(kp + dbase);
+      kv1 = ld8h(kp + dbase + 8);
+      vv0 = ld8h(vp + dbase);
+      vv1 = ld8h(vp + dbase + 8);
+    }
+  };
+  load_tile(0);
   for (int kt = 0; kt < nk; kt += 32) {
-    // ---- stage K [32][128] and V^T [128][32] ----------------------------------------------
-    {
-      const int kid = kt + kr;
-      h8 kv0, kv1, vv0, vv1;
+    // ---- stage K [32][128] and V^T [128][32] (loaded during the previous tile) ---------------
+    *reinterpret_cast<h8*>(Ks + kr * kKP + dbase) = kv0;
+    *reinterpret_cast<h8*>(Ks + kr * kKP + dbase + 8) = kv1;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) kv0[e] = kv1[e] = vv0[e] = vv1[e] = (half_t)0.f;
-      if (kid < nk) {
-        const T *kp, *vp;
-        int fr, r;
-        if (masked) {
-          const int fi = kid / per_frame;
-          r = kid - fi * per_frame;
-          fr = k.t_ind[fi];
-        } else {
-          fr = frame;
-          r = kid;
-        }
-        if (r < kWinTok + 148) {
-          int y, x;
-          if (r < kWinTok) {
-            y = r0 + r / kWinW;
-            x = c0 + r % kWinW;
-          } else {
-            const int ni = r - kWinTok;
-            y = (r0 + (int)k.nb[2 * ni] + k.Hp) % k.Hp;
-            x = (c0 + (int)k.nb[2 * ni + 1] + k.Wp) % k.Wp;
-          }
-          const T* tokp = k.qkv + ((int64_t)(fr * k.Hp + y) * k.Wp + x) * (3 * kDim) + head * kHeadDim;
-          kp = tokp + kDim;
-          vp = tokp + 2 * kDim;
-        } else {
-          const T* tokp = k.pkv + ((int64_t)fr * k.npool + (r - kWinTok - 148)) * (2 * kDim) + head * kHeadDim;
-          kp = tokp;
-          vp = tokp + kDim;
-        }
-        kv0 = ld8h(kp + dbase);
-        kv1 = ld8h(kp + dbase + 8);
-        vv0 = ld8h(vp + dbase);
-        vv1 = ld8h(vp + dbase + 8);
-      }
-      *reinterpret_cast<h8*>(Ks + kr * kKP + dbase) = kv0;
-      *reinterpret_cast<h8*>(Ks + kr * kKP + dbase + 8) = kv1;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        Vt[(dbase + e) * kVP + vblk] = vv0[e];
-        Vt[(dbase + 8 + e) * kVP + vblk] = vv1[e];
-      }
+    for (int e = 0; e < 8; ++e) {
+      Vt[(dbase + e) * kVP + vblk] = vv0[e];
+      Vt[(dbase + 8 + e) * kVP + vblk] = vv1[e];
     }
     __syncthreads();
+    if (kt + 32 < nk) load_tile(kt + 32);
 
     if (wave_live) {
       // ---- S^T = K . Q^T ---------------------------------------------------------------------
