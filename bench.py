@@ -45,11 +45,15 @@ CFG = dict(T=80, H=360, W=640, neighbor_length=10, ref_stride=10, subvideo_lengt
            mask_dilates=5, flow_mask_dilates=8)
 # MI355X dense MFMA peaks (MI355X_MICROARCH.md).  "f32x2" = f32 convolutions computed as three f16 MFMA products per
 # multiply-add (PP_F32X2 operand split): its ceiling for ALGORITHMIC flops is a third of the f16 peak.
-PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32x2": 2500.0 / 3.0}
+# ("direct": the <= 4-output-channel layers run on the vector ALU, conv_direct.hip -- listed under `other`, never dominant)
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32x2": 2500.0 / 3.0, "direct": 157.3}
 KERNEL_NAME = {"f32": "conv_igemm_kernel<float> (pp_conv2d, f32 MFMA implicit GEMM)",
-               "f16": "conv_halo_f16_kernel + conv_igemm_kernel<f16> + conv_ksplit_kernel (pp_conv2d, f16 MFMA implicit GEMM)",
-               "f32x2": "conv_halo_split_kernel + conv_split_kernel (pp_conv2d PP_F32X2: f32 implicit GEMM as 3 f16 MFMA "
-                        "products; halo-tile form for the stride-1 multi-tap convolutions, flat tiles for the rest)"}
+               "f16": "conv_halo_f16_ct_kernel + conv_halo_f16_kernel + conv_igemm_kernel<f16> + conv_ksplit_kernel (pp_conv2d, f16 MFMA "
+                      "implicit GEMM)",
+               "f32x2": "conv_halo_split_ct_kernel + conv_halo_split_kernel + conv_split_kernel (pp_conv2d PP_F32X2: f32 implicit GEMM as 3 "
+                        "f16 MFMA products; halo-tile form with compile-time taps for the 3x3 / 1x5 / 5x1 convolutions, runtime-tap "
+                        "halo tiles for other stride-1 multi-tap shapes, flat tiles for the rest)",
+               "direct": "conv_small_cout_kernel (pp_conv2d, <= 4 output channels: fp32 FMAs on the vector ALU)"}
 
 
 def make_inputs(T, H, W, mask_dilates, flow_mask_dilates, seed=1234):

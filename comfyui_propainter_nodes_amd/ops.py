@@ -301,6 +301,11 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
     if CONV_PROFILE is not None and out.is_cuda:
         flops = 2.0 * n * ho * wo * spec.cout * g * spec.cin_valid * spec.kh * spec.kw
         key = "f16" if x0.dtype == torch.float16 else ("f32x2" if spec.split else "f32")
+        # (the rule of conv_direct.hip's launcher: these launches are streaming vector-ALU kernels, not MFMA tiles)
+        if (spec.cout <= 4 and g == 1 and len(inputs) == 1 and (spec.sh, spec.sw, spec.dh, spec.dw) == (1, 1, 1, 1) and spec.kh <= 3
+                and spec.kw <= 3 and spec.pad_mode == "zeros" and n * ho * wo >= 16384 and os.environ.get("PP_CONV_DIRECT") != "0"
+                and (x0.dtype == torch.float16 or out.dtype == torch.float32)):
+            key = "direct"
         if CONV_PROFILE.detailed:
             key += f"|k{spec.kh}x{spec.kw} cin{spec.cin_valid} cout{spec.cout} g{g} M{n * ho * wo}"
         # algorithmic HBM bytes: every input / weight / epilogue operand read once, the output written once
