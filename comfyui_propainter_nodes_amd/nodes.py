@@ -151,7 +151,19 @@ class _HostImageSink:
         try:
             # first touch of the IMAGE's pages (221 MB for 80 frames of 640x360) while the GPU is still in RAFT: page
             # faults, not arithmetic, are most of the host-side output cost
-            self.image.zero_()
+            # (one plain memset on this thread -- ctypes drops the GIL -- not a multi-threaded torch fill that would compete with
+            # the thread issuing the kernel launches)
+            import ctypes
+
+            ptr, nbytes = self.image.data_ptr(), self.image.numel() * 4
+            try:  # ask for transparent huge pages first (512x fewer faults where the kernel honours MADV_HUGEPAGE)
+                lo = (ptr + (1 << 21) - 1) & ~((1 << 21) - 1)
+                hi = (ptr + nbytes) & ~((1 << 21) - 1)
+                if hi > lo:
+                    ctypes.CDLL(None, use_errno=True).madvise(ctypes.c_void_p(lo), ctypes.c_size_t(hi - lo), 14)
+            except Exception:  # advisory only
+                pass
+            ctypes.memset(ptr, 0, nbytes)
             while True:
                 item = self.q.get()
                 if item is None:
