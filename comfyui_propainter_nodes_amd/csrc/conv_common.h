@@ -368,7 +368,9 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
   // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would, and at most 1/8)
   const int waste256 = (k.Cout + 255) / 256 * 256 - k.Cout;
   const bool fits256 = (k.Cout + 255) / 256 * 256 == (k.Cout + 127) / 128 * 128 && waste256 * 8 <= k.Cout;
-  if (fits256 && (forced == 4 || (forced == 0 && blocks128 >= 1024)))
+  // (f16: from 512 128-wide work-groups on -- the transformer's 1960->512 / 512->512 projections, 864 of them, run 647 / 496
+  // TF/s on the 8-wave tiles against 430 / 341 on 128 x 128 ones; the PP_F32X2 family keeps the validated 1024)
+  if (fits256 && (forced == 4 || (forced == 0 && blocks128 >= F::xl_min_blocks)))
     return F::template run<4, 2, 4, 4>(stream, k, Z);                                // 256 x 128, 8 waves
   if (k.Cout > 64) {
     // 16-pixel tiles when 32-pixel tiles still give at most ~1 work-group per CU

@@ -457,6 +457,7 @@ struct IgemmFamily {
   template <int WC, int WP, int TC, int TP>
   static int run(void* stream, const ConvK& k, int Z) { return launch_cfg<T, OT, WC, WP, TC, TP>(stream, k, Z); }
   static constexpr bool m32_wide96 = sizeof(T) == 4;
+  static constexpr int xl_min_blocks = sizeof(T) == 2 ? 512 : 1024;
 };
 }  // namespace pp
 

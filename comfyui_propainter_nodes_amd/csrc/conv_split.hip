@@ -314,6 +314,7 @@ struct SplitFamily {
   template <int WC, int WP, int TC, int TP>
   static int run(void* stream, const ConvK& k, int Z) { return launch_split_cfg<OT, WC, WP, TC, TP>(stream, k, Z); }
   static constexpr bool m32_wide96 = false;
+  static constexpr int xl_min_blocks = 1024;
 };
 
 int launch_split(void* stream, const ConvK& k, int Z) {

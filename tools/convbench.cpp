@@ -50,6 +50,8 @@ static const std::vector<Shape> SHAPES = {
     {"dcn_offset_f16", PP_F16, 16, 90, 160, {128, 128, 8}, 128, 3, 3, 1, 1},
     {"fc1_f16", PP_F16, 1, 1, 29160, {512}, 1960, 1, 1, 0, 0},
     {"qkv_f16", PP_F16, 1, 1, 27540, {512}, 1536, 1, 1, 0, 0},
+    {"fc2_f16", PP_F16, 1, 1, 27540, {1960}, 512, 1, 1, 0, 0},
+    {"proj_f16", PP_F16, 1, 1, 27540, {512}, 512, 1, 1, 0, 0},
     {"rfc_step_f16", PP_F16, 2, 45, 80, {128, 128}, 128, 3, 3, 1, 1},
     {"rfc_off0_f16", PP_F16, 2, 45, 80, {128, 128, 128}, 128, 3, 3, 1, 1},
     {"rfc_bb2_f16", PP_F16, 2, 45, 80, {128}, 128, 3, 3, 1, 1},
