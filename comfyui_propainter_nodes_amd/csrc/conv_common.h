@@ -50,6 +50,7 @@ struct ConvK {
   int nchunks;
   const void* pre_add;
   int pre_add_ldc;
+  const float* weight_f32;  // optional fp32 [tap][chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float param) {

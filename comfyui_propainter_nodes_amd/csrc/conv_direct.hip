@@ -18,7 +18,7 @@ namespace pp {
 
 constexpr int kDirT = 16;  // output tile edge
 
-template <typename T, typename OT, int COUT>
+template <typename T, typename OT, int COUT, bool WG>
 __global__ void __launch_bounds__(256) conv_small_cout_kernel(const ConvK p, const int tiles_x, const int tiles_y, const int wmode) {
   constexpr int EPP = 16 / (int)sizeof(T);       // elements per 16-byte piece
   constexpr int PP_ = 32 / EPP;                  // pieces per pixel and 32-channel chunk (8 fp32, 4 f16)
@@ -28,15 +28,18 @@ __global__ void __launch_bounds__(256) conv_small_cout_kernel(const ConvK p, con
   const int ntaps = p.kh * p.kw;
   const int nck = p.chunks_per_tap;              // one segment: chunks of the input
   const int hw = kDirT + p.kw - 1, hrows = (kDirT + p.kh - 1) * hw;
-  float* wl = reinterpret_cast<float*>(smem);    // [tap][chunk][COUT][32]
-  unsigned char* xt = smem + (size_t)ntaps * nck * COUT * 32 * sizeof(float);
+  // weights as fp32 [tap][chunk][COUT][32]: WG = the caller's table in global memory (wave-uniform addresses: hipcc reads
+  // them with scalar loads, they never touch LDS), else decoded here into LDS
+  float* wl = reinterpret_cast<float*>(smem);
+  unsigned char* xt = smem + (WG ? (size_t)0 : (size_t)ntaps * nck * COUT * 32 * sizeof(float));
+  const float* __restrict__ wg = p.weight_f32;
 
   const int bid = (int)blockIdx.x;
   const int txi = bid % tiles_x, tyi = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
   const int ty0 = tyi * kDirT, tx0 = txi * kDirT;
 
   // ---- weights -> fp32 in LDS (wmode: the packing of p.weight, PP_F32 / PP_F16 / PP_F32X2)
-  for (int i = tid; i < ntaps * nck * COUT * 32; i += 256) {
+  for (int i = tid; !WG && i < ntaps * nck * COUT * 32; i += 256) {
     const int j = i & 31, co = (i >> 5) % COUT, tk = (i >> 5) / COUT;  // tk = tap * nck + chunk
     float w;
     if (co >= p.Cout) {
@@ -75,7 +78,7 @@ __global__ void __launch_bounds__(256) conv_small_cout_kernel(const ConvK p, con
     for (int tap = 0; tap < ntaps; ++tap) {
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
       const unsigned char* xp = xt + ((ty + ky) * hw + tx + kx) * PITCH;
-      const float* wp = wl + (tap * nck + k) * COUT * 32;
+      const float* wp = (WG ? wg : wl) + (tap * nck + k) * COUT * 32;
 #pragma unroll
       for (int j = 0; j < PP_; ++j) {
         if constexpr (sizeof(T) == 2) {
@@ -146,18 +149,22 @@ static int launch_direct_t(void* stream, const ConvK& k, int wmode) {
   const int64_t blocks = (int64_t)k.N * tiles_x * tiles_y;
   const int hrows = (kDirT + k.kh - 1) * (kDirT + k.kw - 1);
   const int cmax = k.Cout <= 2 ? 2 : 4;
-  const size_t smem = (size_t)k.nchunks * cmax * 32 * sizeof(float) + (size_t)hrows * (32 * sizeof(T) + 16);
+  const bool wg = k.weight_f32 != nullptr;
+  const size_t smem = (wg ? 0 : (size_t)k.nchunks * cmax * 32 * sizeof(float)) + (size_t)hrows * (32 * sizeof(T) + 16);
   if (smem > 150 * 1024 || blocks >= ((int64_t)1 << 31)) return 1;
   dim3 grid((unsigned)blocks), block(256);
+#define PP_DIRECT_LAUNCH(C, W)                                                                                              \
+  do {                                                                                                                      \
+    static const bool ok_ = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_small_cout_kernel<T, OT, C, W>), 150 * 1024), true); \
+    (void)ok_;                                                                                                              \
+    PP_LAUNCH((conv_small_cout_kernel<T, OT, C, W>), grid, block, smem, stream, k, tiles_x, tiles_y, wmode);                \
+  } while (0)
   if (cmax == 2) {
-    static const bool ok2 = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_small_cout_kernel<T, OT, 2>), 150 * 1024), true);
-    (void)ok2;
-    PP_LAUNCH((conv_small_cout_kernel<T, OT, 2>), grid, block, smem, stream, k, tiles_x, tiles_y, wmode);
+    if (wg) PP_DIRECT_LAUNCH(2, true); else PP_DIRECT_LAUNCH(2, false);
   } else {
-    static const bool ok4 = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_small_cout_kernel<T, OT, 4>), 150 * 1024), true);
-    (void)ok4;
-    PP_LAUNCH((conv_small_cout_kernel<T, OT, 4>), grid, block, smem, stream, k, tiles_x, tiles_y, wmode);
+    if (wg) PP_DIRECT_LAUNCH(4, true); else PP_DIRECT_LAUNCH(4, false);
   }
+#undef PP_DIRECT_LAUNCH
   return pp_check_launch("pp_conv2d");
 }
 

@@ -514,6 +514,7 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   k.aux1 = p->aux1; k.aux1_ldc = (int)p->aux1_ldc; k.aux1_zoff = p->aux1_zoff;
   k.aux2 = p->aux2; k.aux2_ldc = (int)p->aux2_ldc; k.aux2_zoff = p->aux2_zoff;
   k.pre_add = p->pre_add; k.pre_add_ldc = (int)p->pre_add_ldc;
+  k.weight_f32 = reinterpret_cast<const float*>(p->weight_f32);
   if (p->pre_add && p->Z != 1) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: pre_add with Z > 1");
   const int Z = (int)p->Z;
   if (k.Cout <= 4) {  // 2-3 output channels on a 32-channel MFMA tile are wasted matrix work: streaming vector-ALU kernel

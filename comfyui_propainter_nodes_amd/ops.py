@@ -193,9 +193,12 @@ class ConvSpec:
     pad_mode: str = "zeros"
     cin_valid: int = 0            # real (unpadded) input channels per group, for FLOP accounting
     split: bool = False           # f32 tensors on the f16 matrix pipe (PP_F32X2 weight packing)
+    weight_f32: torch.Tensor | None = None  # Cout <= 4 only: fp32 [tap*chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
 
     def to(self, device) -> "ConvSpec":
         self.weight = self.weight.to(device)
+        if self.weight_f32 is not None:
+            self.weight_f32 = self.weight_f32.to(device)
         if self.bias is not None:
             self.bias = self.bias.to(device)
         return self
@@ -218,13 +221,20 @@ def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, 
     dh, dw = pair(dilation)
     seg_channels = seg_channels or [cin_g]
     packed = pack_conv_weight(w, seg_channels, dtype, seg_valid)
+    table = None
+    if cout <= 4 and groups == 1 and len(seg_channels) == 1 and os.environ.get("PP_CONV_DIRECT_TABLE") != "0":
+        # the values the MFMA path would multiply with (f16 weights stay f16-rounded), as fp32, chunk-major
+        t = packed.float().reshape(cout, packed.shape[1] // 32, 32).permute(1, 0, 2)
+        table = torch.zeros(t.shape[0], 2 if cout <= 2 else 4, 32)
+        table[:, :cout] = t
+        table = table.contiguous()
     if split:
         if dtype != torch.float32:
             raise TypeError("split packing applies to f32 convolutions only")
         packed = split_pack_weight(packed)
     bias = b.detach().float().contiguous() if b is not None else None
     return ConvSpec(packed, bias, list(seg_channels), cout // groups, kh, kw, sh, sw, ph, pw, dh, dw, groups, pad_mode,
-                    sum(seg_valid) if seg_valid else cin_g, split)
+                    sum(seg_valid) if seg_valid else cin_g, split, table)
 
 
 def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
@@ -293,6 +303,8 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
         P.aux2 = aux2.data_ptr()
         P.aux2_ldc = nhwc_view(aux2)[4]
         P.aux2_zoff = spec.cout if g > 1 else 0
+    if spec.weight_f32 is not None:
+        P.weight_f32 = spec.weight_f32.data_ptr()
     if pre_add is not None:
         if pre_add.dtype != out.dtype:
             raise TypeError("pre_add dtype must match out dtype")

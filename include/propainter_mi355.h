@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 4
+#define PP_ABI_VERSION 5
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -124,6 +124,10 @@ typedef struct {
   const void* pre_add; /* optional [N][Ho][Wo][Cout] (out dtype) added BEFORE the activation: a partial
                           convolution over constant input channels computed once (RAFT GRU context term) */
   int64_t pre_add_ldc;
+  const void* weight_f32; /* optional (ABI v5), only read when Cout <= 4: the same weights as fp32
+                             [tap][32-channel chunk][Cout padded to 2 or 4][32] for the vector-ALU kernel of the 2-3
+                             channel layers (conv_direct.hip reads them through the scalar cache instead of decoding
+                             `weight` into LDS per work-group); NULL = decode from `weight` */
 } pp_conv2d_params;
 
 int32_t pp_conv2d(void* stream, const pp_conv2d_params* p);

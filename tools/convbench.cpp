@@ -116,6 +116,12 @@ static void run(const Shape& s, int iters) {
   void* w = device_random((size_t)s.Cout * kp * (s.dtype == PP_F32X2 ? 2 : 1), s.dtype == PP_F32 ? 4 : 2, 0.1f);
   bufs.push_back(w);
   p.weight = w;
+  if (s.Cout <= 4 && p.nseg == 1 && !(getenv("PP_CONV_DIRECT_TABLE") && getenv("PP_CONV_DIRECT_TABLE")[0] == '0')) {
+    // the optional fp32 [tap * chunk][Cout padded to 2 / 4][32] table of the <= 4-channel layers (timing only: random values)
+    void* t = device_random((size_t)(kp / 32) * (s.Cout <= 2 ? 2 : 4) * 32, 4, 0.1f);
+    bufs.push_back(t);
+    p.weight_f32 = t;
+  }
   p.Cout = s.Cout;
   p.Z = 1;
   const size_t on = (size_t)s.N * p.Ho * p.Wo * s.Cout;
