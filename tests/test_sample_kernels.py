@@ -69,3 +69,49 @@ def test_rfc_prep_and_combine(backend):
     ref0 = pf * m[:-1, ..., None] + flows[0] * (1 - m[:-1, ..., None])
     ref1 = pb * m[1:, ..., None] + flows[1] * (1 - m[1:, ..., None])
     assert torch.allclose(out.cpu()[0], ref0) and torch.allclose(out.cpu()[1], ref1)
+
+
+def test_deform_conv_hand_computed_samples(backend):
+    """An independent pin of the deform_conv2d contract (oracle, fixtures and kernel all descend from
+    oracle/ops.py).  The expected numbers below are worked out BY HAND from torchvision's documented rule -- sample position
+    (y - pad + i + dy, x - pad + j + dx), bilinear, a sample with h <= -1, h >= H, w <= -1 or w >= W is 0 and every
+    out-of-range corner contributes 0 -- on an image that is linear in (y, x), so an interior sample is the linear function
+    itself.  Checked for the oracle AND for pp_deform_cols + pp_conv2d."""
+    dev = backend
+    n, h, w, cin, dg, K = 1, 6, 7, 32, 16, 9
+    ci, tap = 3, 4                      # channel 3 -> offset group 3 // (32 / 16) = 1; tap 4 = (i, j) = (1, 1): base position (y, x)
+    grp = ci // (cin // dg)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    x = torch.zeros(n, h, w, cin)
+    x[0, :, :, ci] = 4.0 * (10.0 * yy + xx)          # f(y, x) = 4 (10 y + x): exact in f16 on this grid
+    off = torch.zeros(n, h, w, 2 * dg * K)
+    msk = torch.ones(n, h, w, dg * K)
+    dy_c, dx_c, m_c = grp * 2 * K + 2 * tap, grp * 2 * K + 2 * tap + 1, grp * K + tap
+    cases = [  # (y, x, dy, dx, mask, expected)
+        (2, 3, 0.5, 0.25, 1.0, 4.0 * (10 * 2.5 + 3.25)),           # interior: the linear function at (2.5, 3.25) = 113
+        (0, 2, -0.5, 0.0, 1.0, 0.5 * 4.0 * 2.0),                   # h = -0.5: row -1 contributes 0, row 0 with weight 0.5 -> 4
+        (0, 1, -1.0, 0.0, 1.0, 0.0),                               # h = -1 exactly: outside
+        (1, w - 1, 0.0, 0.5, 1.0, 0.5 * 4.0 * (10 + (w - 1))),     # w = W - 0.5: column W contributes 0 -> 32
+        (3, w - 1, 0.0, 1.0, 1.0, 0.0),                            # w = W exactly: outside
+        (4, 4, 0.0, 0.0, 0.25, 0.25 * 4.0 * 44.0),                 # modulation mask -> 44
+        (5, 0, 0.75, -0.5, 1.0, 0.25 * 0.5 * 4.0 * 50.0),          # h = 5.75, w = -0.5: only corner (5, 0), weight 0.25 * 0.5 -> 25
+    ]
+    for (y, xq, dy, dx, m, _) in cases:
+        off[0, y, xq, dy_c], off[0, y, xq, dx_c], msk[0, y, xq, m_c] = dy, dx, m
+    wgt = torch.zeros(8, cin, 3, 3)
+    wgt[0, ci, 1, 1] = 1.0              # output channel 0 = mask * sample of channel `ci` at tap (1, 1)
+    ref = deform_conv2d(x.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), wgt, None, 1, 1, 1, msk.permute(0, 3, 1, 2))[0, 0]
+    cols = torch.empty(n, h, w, 9 * cin, device=dev, dtype=torch.float16)
+    ops.deform_cols(x.half().to(dev), None, torch.cat([off, msk], -1).to(dev), cols, dg=dg)
+    spec = ops.make_conv_spec(wgt.permute(0, 2, 3, 1).reshape(8, 9 * cin, 1, 1), None, torch.float16).to(dev)
+    out = torch.empty(n, h, w, 8, device=dev, dtype=torch.float16)
+    ops.conv2d(spec, [cols], out)
+    got = out[0, :, :, 0].float().cpu()
+    for (y, xq, _, _, _, want) in cases:
+        assert abs(ref[y, xq].item() - want) < 1e-4, ("oracle", y, xq, ref[y, xq].item(), want)
+        assert abs(got[y, xq].item() - want) < 1e-2 + 1e-3 * abs(want), ("kernel", y, xq, got[y, xq].item(), want)
+    # everywhere else the offsets are zero: the centre tap reproduces the image
+    untouched = torch.ones(h, w, dtype=torch.bool)
+    for (y, xq, *_rest) in cases:
+        untouched[y, xq] = False
+    assert torch.allclose(ref[untouched], x[0, :, :, ci][untouched]) and torch.allclose(got[untouched], x[0, :, :, ci][untouched])
