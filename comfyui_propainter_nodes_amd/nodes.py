@@ -176,6 +176,10 @@ class _HostImageSink:
         except BaseException as e:  # surfaced by finish()
             self.error = e
 
+    def abandon(self) -> None:
+        self.q.put(None)
+        self.worker.join(timeout=5.0)
+
     def finish(self) -> torch.Tensor:
         self.q.put(None)
         self.worker.join()
@@ -192,7 +196,12 @@ def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer):
         TRACE.update(frames_u8=fr_u8, flow_masks=fm, masks_dilated=md)
     stream_out = fr_u8.is_cuda and os.environ.get("PP_OUTPUT", "stream") == "stream" and TRACE is None
     sink = _HostImageSink(*fr_u8.shape[:3], fr_u8.device) if stream_out else None
-    comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32, sink=sink)
+    try:
+        comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32, sink=sink)
+    except BaseException:
+        if sink is not None:
+            sink.abandon()             # release the worker thread: a failed call must not leave it parked on the queue
+        raise
     tm.mark("pipeline")
     if sink is not None:
         out = (sink.finish(), fm.float().squeeze(), md.float().squeeze())
