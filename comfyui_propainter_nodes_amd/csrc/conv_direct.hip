@@ -6,9 +6,10 @@
 // 4.5 MB of output) held at a fifth of the HBM rate by wasted matrix work.  Here it is what it is, a streaming
 // reduction on the vector ALU (fp32 FMAs: PP_F32X2's three-product f16 arithmetic is only an fp32 stand-in):
 //   - a 256-thread work-group owns a 16 x 16 output tile, one output pixel per thread, COUT fp32 accumulators;
-//   - per 32-channel chunk the (16 + kh - 1) x (16 + kw - 1) input tile is read once with coalesced 16-byte loads
-//     into LDS (pixel pitch = chunk bytes + 16, an odd number of 16-byte slots: a wave's ds_read_b128 of 64 different
-//     pixels is conflict free up to the tile-row wrap), every tap then reads its channels from there;
+//   - per 32-channel chunk the (16 + kh - 1) x (16 + kw - 1) input tile is read once with coalesced 16-byte loads (into
+//     registers, one chunk ahead of the FMAs) and stored into LDS (pixel pitch = chunk bytes + 16, an odd number of
+//     16-byte slots: a wave's ds_read_b128 of 64 different pixels is conflict free up to the tile-row wrap), every tap
+//     then reads its channels from there;
 //   - the weights are decoded ONCE per work-group into LDS as fp32 (from the packed f16 / PP_F32X2 / f32 layouts of
 //     ops.pack_conv_weight) and read as wave-uniform (broadcast) ds_read_b128.
 // Epilogue = store_quad's arithmetic per scalar (bias, pre_add, activation split, scale, fused op), any output view.
@@ -61,20 +62,39 @@ __global__ void __launch_bounds__(256) conv_small_cout_kernel(const ConvK p, con
 #pragma unroll
   for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
 
+  // ---- the thread's pieces of the input tile: global offset (-1 = outside the image: zero) and LDS offset (-1 = past the
+  // tile), fixed for the whole kernel; the pieces of chunk k+1 are loaded into registers while chunk k is multiplied
+  constexpr int MAXP = (18 * 18 * PP_ + 255) / 256;
+  int64_t goff[MAXP];
+  int loff[MAXP], cpos[MAXP];
+#pragma unroll
+  for (int q = 0; q < MAXP; ++q) {
+    const int i = tid + q * 256;
+    const int hr = i / PP_, j = i - hr * PP_;
+    const int hy = hr / hw, hx = hr - hy * hw;
+    const int iy = ty0 - p.ph + hy, ix = tx0 - p.pw + hx;
+    const bool in_tile = i < hrows * PP_;
+    const bool in_img = in_tile && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    goff[q] = in_img ? ((int64_t)(n * p.H + iy) * p.W + ix) * p.in_ldc[0] + j * EPP : -1;
+    loff[q] = in_tile ? hr * PITCH + j * 16 : -1;
+    cpos[q] = j * EPP;
+  }
+  f4 xr[MAXP];
+  auto load_chunk = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) {
+      xr[q] = f4{0.f, 0.f, 0.f, 0.f};
+      if (goff[q] >= 0 && k * 32 + cpos[q] < p.in_C[0]) xr[q] = *reinterpret_cast<const f4*>(in + goff[q] + k * 32);
+    }
+  };
+  load_chunk(0);
   for (int k = 0; k < nck; ++k) {
     __syncthreads();                             // the previous chunk's readers are done (and, first, the weights are stored)
-    // ---- input tile of this chunk: 16-byte pieces, consecutive threads = consecutive pieces of a pixel
-    for (int i = tid; i < hrows * PP_; i += 256) {
-      const int hr = i / PP_, j = i - hr * PP_;
-      const int hy = hr / hw, hx = hr - hy * hw;
-      const int iy = ty0 - p.ph + hy, ix = tx0 - p.pw + hx;
-      const int c = k * 32 + j * EPP;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.in_C[0])
-        v = *reinterpret_cast<const f4*>(in + ((int64_t)(n * p.H + iy) * p.W + ix) * p.in_ldc[0] + c);
-      *reinterpret_cast<f4*>(xt + hr * PITCH + j * 16) = v;
-    }
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q)
+      if (loff[q] >= 0) *reinterpret_cast<f4*>(xt + loff[q]) = xr[q];
     __syncthreads();
+    if (k + 1 < nck) load_chunk(k + 1);          // in flight under this chunk's FMAs
     for (int tap = 0; tap < ntaps; ++tap) {
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
       const unsigned char* xp = xt + ((ty + ky) * hw + tx + kx) * PITCH;
