@@ -395,6 +395,11 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
   return F::template run<1, 4, 1, 4>(stream, k, Z);                                  //  16 x 256
 }
 
+// flat-tile implicit-GEMM families (conv_igemm_kernel.h), one translation unit each
+int launch_igemm_hh(void* stream, const ConvK& k, int Z);                 // f16 tensors, f16 output
+int launch_igemm_hf(void* stream, const ConvK& k, int Z);                 // f16 tensors, f32 output
+int launch_igemm_ff(void* stream, const ConvK& k, int Z);                 // f32 tensors (exact f32 MFMA products), f32 output
+int launch_igemm_fh(void* stream, const ConvK& k, int Z);                 // f32 tensors, f16 output
 // f32 convolution on the f16 matrix pipe (PP_F32X2): conv_split.hip
 int launch_split(void* stream, const ConvK& k, int Z);
 // f16 convolutions with few output pixels and a long reduction (conv_ksplit.hip); returns 1 when not eligible
