@@ -67,6 +67,20 @@ def window_schedule(config: ProPainterConfig) -> list[tuple[list[int], list[int]
     return out
 
 
+def final_ranges(schedule, video_length: int) -> list[tuple[int, int]]:
+    """Per window (lo, hi): the frames that have received their LAST blend once that window is composed -- no later
+    window has them among its local frames -- as consecutive half-open ranges that tile [0, video_length) (hi == lo for a
+    window that finishes nothing).  The local-frame ranges of window_schedule() slide forward monotonically, so the
+    frames before the next window's first local frame are final."""
+    out, done = [], 0
+    for wi in range(len(schedule)):
+        nxt = min(schedule[wi + 1][0]) if wi + 1 < len(schedule) else video_length
+        nxt = max(nxt, done)
+        out.append((done, nxt))
+        done = nxt
+    return out
+
+
 @dataclass
 class Models:
     raft_model: RaftFlow
@@ -239,20 +253,15 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     schedule, spans, table = device_schedule(config)
     props = gen.propagate_windows(st, [nb for nb, _ in schedule])
     mark("feature_propagation(all windows batched)")
-    done = 0  # frames [0, done) are final
+    finals = final_ranges(schedule, T) if sink is not None else None
     for wi, (nb, refs) in enumerate(schedule):
         out = gen.forward_window(st, nb, refs, local_prop=props[wi])
         a, b = spans[wi]
         ops.compose_u8(out, table[0, a:b], table[1, a:b], md, fr_u8, comp)
         if trace is not None:
             trace["pred_imgs"].append(out[..., :3].float().cpu())
-        if sink is not None:
-            # the windows slide forward (pipeline.window_schedule): everything before the next window's first local frame
-            # has received its last blend
-            nxt = min(schedule[wi + 1][0]) if wi + 1 < len(schedule) else T
-            if nxt > done:
-                sink.frames_final(comp, done, nxt)
-                done = nxt
+        if finals is not None and finals[wi][1] > finals[wi][0]:
+            sink.frames_final(comp, *finals[wi])     # these frames can no longer change: stream them out
     mark("windows(transformer+decoder+compose)")
     if timing:
         print("[pp] stage ms: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f}" for a, b in zip(marks, marks[1:])), flush=True)

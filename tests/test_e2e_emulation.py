@@ -23,8 +23,18 @@ def test_whole_pipeline_under_emulation_matches_oracle(emu_lib, monkeypatch):
     dev = torch.device("cpu")
     models = pipeline.models_from_state_dicts(sds, dev)
     cfg = pipeline.ProPainterConfig(2, 2, 80, 1, "enable", T, dev, (W, H))
+    class Sink:  # the node's streaming hook: every reported range must already hold its final pixels
+        def __init__(self):
+            self.parts = []
+
+        def frames_final(self, comp, lo, hi):
+            self.parts.append((lo, hi, comp[lo:hi].clone()))
+
+    sink = Sink()
     got = pipeline.run_inpainting(models, torch.from_numpy(fr), torch.from_numpy(fm), torch.from_numpy(md), cfg,
-                                  to_host=False).numpy()
+                                  to_host=False, sink=sink).numpy()
+    assert [p[:2] for p in sink.parts][0][0] == 0 and sink.parts[-1][1] == T
+    assert all(np.array_equal(part.numpy(), got[lo:hi]) for lo, hi, part in sink.parts)
     frames = (torch.from_numpy(fr).float().div(255) * 2 - 1).permute(0, 3, 1, 2)[None]
     torch.set_num_threads(8)
     ref = np.stack(OP.run(sds, frames, torch.from_numpy(fm).float()[None, :, None], torch.from_numpy(md).float()[None, :, None],

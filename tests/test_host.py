@@ -108,3 +108,22 @@ def test_survey_window_counts():
         cfg = pipeline.ProPainterConfig(rs, nl, sv, 20, "enable", T, torch.device("cuda"), (640, 360))
         s = pipeline.window_schedule(cfg)
         assert (len(s), sum(len(a) for a, _ in s), sum(len(a) + len(b) for a, b in s)) == (nwin, sum_lt, sum_t)
+
+
+@pytest.mark.parametrize("T,nl,rs,sv", [(80, 10, 10, 80), (13, 4, 3, 80), (2, 2, 2, 80), (31, 6, 5, 10), (100, 20, 10, 80), (7, 300, 1, 80)])
+def test_final_ranges_tile_the_clip_and_are_really_final(T, nl, rs, sv):
+    """The node streams frames out as soon as pipeline.final_ranges says no later window blends into them: the ranges
+    must tile [0, T) in order, and no frame of a range may be a local frame of a LATER window (checked by brute force
+    on the reference's own window schedule)."""
+    from comfyui_propainter_nodes_amd import pipeline
+
+    cfg = pipeline.ProPainterConfig(rs, nl, sv, 1, "enable", T, "cpu", (64, 64))
+    sched = pipeline.window_schedule(cfg)
+    fin = pipeline.final_ranges(sched, T)
+    assert len(fin) == len(sched) and fin[0][0] == 0 and fin[-1][1] == T
+    assert all(a <= b for a, b in fin) and all(fin[i][1] == fin[i + 1][0] for i in range(len(fin) - 1))
+    for wi, (lo, hi) in enumerate(fin):
+        later = {f for nb, _ in sched[wi + 1:] for f in nb}
+        assert not (set(range(lo, hi)) & later), (wi, lo, hi)
+        # ... and nothing is held back longer than necessary: the first frame after the range is still needed (or the clip ends)
+        assert hi == T or hi in later
