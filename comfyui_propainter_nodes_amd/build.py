@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -26,10 +27,6 @@ def _sources() -> list[Path]:
     return sorted(CSRC.glob("*.hip"))
 
 
-def _headers() -> list[Path]:
-    return sorted(CSRC.glob("*.h")) + sorted((ROOT / "include").glob("*.h"))
-
-
 def _digest(paths: list[Path], extra: str) -> str:
     h = hashlib.sha256(extra.encode())
     for p in paths:
@@ -45,17 +42,37 @@ def _run(cmd: list[str]) -> None:
         raise RuntimeError(f"build failed: {cmd[0]}")
 
 
-def _compile_all(objs_dir: Path, compile_one, link, out: Path, stamp_extra: str, force: bool) -> Path:
+_INCLUDE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+
+
+def _local_deps(src: Path, extra_dirs: tuple[Path, ...] = ()) -> list[Path]:
+    """The repo headers a translation unit includes (transitively): a unit is rebuilt only when one of THEM changes."""
+    seen: dict[Path, None] = {}
+    todo = [src]
+    dirs = (CSRC, ROOT / "include") + tuple(extra_dirs)
+    while todo:
+        f = todo.pop()
+        for name in _INCLUDE.findall(f.read_text()):
+            for d in (f.parent,) + dirs:
+                h = (d / name).resolve()
+                if h.exists():
+                    if h not in seen:
+                        seen[h] = None
+                        todo.append(h)
+                    break
+    return sorted(seen)
+
+
+def _compile_all(objs_dir: Path, compile_one, link, out: Path, stamp_extra: str, force: bool,
+                 extra_dirs: tuple[Path, ...] = ()) -> Path:
     srcs = _sources()
-    hdrs = _headers()
     objs_dir.mkdir(parents=True, exist_ok=True)
-    hdr_digest = _digest(hdrs, stamp_extra)
     objs = []
     jobs = []
     for s in srcs:
         o = objs_dir / (s.stem + ".o")
         stamp = objs_dir / (s.stem + ".stamp")
-        want = _digest([s], hdr_digest)
+        want = _digest([s] + _local_deps(s, extra_dirs), stamp_extra)
         objs.append(o)
         if force or not o.exists() or not stamp.exists() or stamp.read_text() != want:
             jobs.append((s, o, stamp, want))

@@ -233,16 +233,20 @@ static int launch_ksplit_t(void* stream, const ConvK& k, int Z) {
   return pp_check_launch("pp_conv2d");
 }
 
-// returns 1 when the problem is not a small-M / long-K one (the caller uses the regular tiles).
+// returns 1 when the problem is not a small-image / long-K one (the caller uses the regular tiles).  The decision is a
+// function of the LAYER (pixels of one image, Cout, K) and never of the batch: split-K sums the chunks in a different
+// order than the flat tiles, and a rank of a sharded run that batches fewer windows / frames than the single-GPU run must
+// still pick the same kernel for the same layer so that both runs agree bit for bit (r02 decided on N*Ho*Wo).
 // PP_CONV_KSPLIT=0 disables, "force" selects it for every f16 problem with at least 4 chunks (tests).
 int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16) {
   const char* e = getenv("PP_CONV_KSPLIT");
   const int mode = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'f' ? 2 : 1));
   if (mode == 0 || k.nchunks < kKS) return 1;
   if (mode != 2) {
-    const int64_t blocks32 = ((k.M + 31) / 32) * ((k.Cout + 127) / 128) * Z;
-    // at most ~1.25 work-groups per CU with 32-pixel tiles, and a reduction worth splitting (>= 8 chunks per group)
-    if (blocks32 > 320 || k.nchunks < 8 * kKS || k.Cout <= 64) return 1;
+    const int64_t img_blocks32 = (((int64_t)k.Ho * k.Wo + 31) / 32) * ((k.Cout + 127) / 128);
+    // an image of at most ~160 32-pixel tiles (45x80 of flow completion: 113) and a reduction worth splitting
+    // (>= 8 chunks per group)
+    if (img_blocks32 > 160 || k.nchunks < 8 * kKS || k.Cout <= 64) return 1;
   }
   return out_f16 ? launch_ksplit_t<half_t>(stream, k, Z) : launch_ksplit_t<float>(stream, k, Z);
 }

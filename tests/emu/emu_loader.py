@@ -28,7 +28,7 @@ def build_emu(force: bool = False) -> Path:
         B._run([HOST_CLANG, "-shared", "-fPIC", *map(str, objs), str(rt), "-lpthread", "-o", str(out)])
 
     extra = "emu" + " ".join(flags) + (EMU_DIR / "pp_emu.h").read_text() + (EMU_DIR / "pp_emu.cpp").read_text()
-    return B._compile_all(EMU_DIR / "build", compile_one, link, EMU_LIB, extra, force)
+    return B._compile_all(EMU_DIR / "build", compile_one, link, EMU_LIB, extra, force, extra_dirs=(EMU_DIR,))
 
 
 def load_emulator() -> lib.Library:

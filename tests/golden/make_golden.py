@@ -186,7 +186,7 @@ def _rel(a, b):
 
 def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_length, ref_stride, subvideo_length,
                   mask_dilates=5, flow_mask_dilates=8, width_scale=1.2, height_scale=1.0, seed=0, flow_stride=4,
-                  save=True, check_oracle=True):
+                  save=True, check_oracle=True, mask_kind="static"):
     """BASELINE-config fixtures minted THROUGH THE REFERENCE'S NODE METHODS (propainter_nodes.py:93-154 / :231-310),
     fp16 "disable" on CPU, with the stage tensors captured on the way.  Stored compactly (the inputs are regenerable
     from the seed): RAFT flows as f32 on a 2*`flow_stride` sub-grid, completed flows as f16 on a `flow_stride` sub-grid, updated masks bit-packed, the node's IMAGE output only
@@ -218,6 +218,8 @@ def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_len
     RN.process_inpainting = pi
     RN.initialize_models = lambda device, fp16: models
     image, mask = synth.synthetic_clip(T, H, W)
+    if mask_kind == "moving":
+        mask = synth.moving_mask(T, H, W)
     common = dict(mask_dilates=mask_dilates, flow_mask_dilates=flow_mask_dilates, ref_stride=ref_stride,
                   neighbor_length=neighbor_length, subvideo_length=subvideo_length, raft_iter=raft_iter, fp16="disable")
     t0 = time.time()
@@ -259,7 +261,7 @@ def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_len
             HERE / f"{name}.npz",
             kind=np.array(kind), params_json=np.array(__import__("json").dumps(dict(
                 T=T, H=H, W=W, width=width, height=height, width_scale=width_scale, height_scale=height_scale, seed=seed,
-                flow_stride=s, **common))),
+                flow_stride=s, mask_kind=mask_kind, **common))),
             gt_flow=np.stack([cap["gt"][i][0, :, :, ::2 * s, ::2 * s].numpy() for i in (0, 1)], 0).astype(np.float32),
             pred_flow=np.stack([cap["pred"][i][0, :, :, ::s, ::s].numpy() for i in (0, 1)], 0).astype(np.float16),
             updated_masks=np.packbits(cap["um"][0, :, 0].numpy().astype(np.uint8)),
@@ -282,6 +284,16 @@ NODE_CASES = {
     # configs[2] geometry: outpaint 640x360 -> 768x360 canvas (64-px borders), 12-frame truncation
     "cfg3_12f_node": dict(kind="outpaint", T=12, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
                           ref_stride=10, subvideo_length=80),
+    # configs[1] in full: the 80-frame clip bench.py times (its `parity` leg compares the TIMED output with this fixture)
+    "cfg2_80f_node": dict(kind="inpaint", T=80, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                          ref_stride=10, subvideo_length=80, flow_stride=8),
+    # configs[3]'s mode at its size: T > subvideo_length -> local reference frames (ref_num 8), flow completion in
+    # sub-videos of 80 with 5-frame halos, image propagation in sub-videos of 80 with 10-frame halos
+    "cfg4_100f_node": dict(kind="inpaint", T=100, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                           ref_stride=10, subvideo_length=80, flow_stride=8),
+    # per-frame (moving) MASK input, mask.shape[0] == T: one dilation per mask frame (image_utils.py:142-175)
+    "mov_20f_node": dict(kind="inpaint", T=20, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                         ref_stride=10, subvideo_length=80, mask_kind="moving"),
 }
 
 
@@ -299,6 +311,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default="all")
     ap.add_argument("--no-save", action="store_true")
+    ap.add_argument("--no-oracle", action="store_true", help="skip the oracle pin of a node case (halves the time)")
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.case in ("all", "host"):
@@ -308,7 +321,7 @@ def main():
             run_case(name, save=not args.no_save, **kw)
     for name, kw in NODE_CASES.items():
         if args.case in ("all", name):
-            run_node_case(name, save=not args.no_save, **kw)
+            run_node_case(name, save=not args.no_save, check_oracle=not args.no_oracle, **kw)
 
 
 if __name__ == "__main__":
