@@ -7,6 +7,7 @@
 #include "attn_device.h"
 #include "pp_host.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace pp {
@@ -276,7 +277,8 @@ struct AttnF16K {
   half_t* out;
   int t, nt, Hp, Wp, fh, fw, npool, nww;
   int nx;        // work-groups per (head, window): max(128-query blocks of a masked window, frame pairs)
-  int nwg;       // total work-groups
+  int npairs;    // (window, head) pairs
+  int dbg;
   float scale_log2e;
   signed char nb[148 * 2];
 };
@@ -287,11 +289,14 @@ constexpr int kAtHalf = kAtTile * kAtRow;       // K (or V) bytes per stage
 constexpr int kAtStage = 2 * kAtHalf;           // K | V
 constexpr int kAtSpatial = kWinTok + 148;       // own + rolled-neighbour tokens per key frame
 constexpr int kAtMaxNt = 1024;
-constexpr int kAtSmem = 2 * kAtStage + (kAtSpatial + 3 + kAtMaxNt) * 4;
+constexpr int kAtTabs = 2 * kAtStage;                                  // [rowtab 2 x 64 x i64][koff][tind]
+constexpr int kAtSmem = kAtTabs + 2 * kAtTile * 8 + (kAtSpatial + 3 + kAtMaxNt) * 4;
+static_assert(kHeads == 4, "pair decoding");
 
 __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const AttnF16K k) {
-  unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);  // [stage 0: K | V][stage 1: K | V][koff][tind]
-  int* koff = reinterpret_cast<int*>(smem + 2 * kAtStage);
+  unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);  // [stage 0: K | V][stage 1: K | V][rowtab][koff][tind]
+  int64_t* rowtab = reinterpret_cast<int64_t*>(smem + kAtTabs);         // [2][64]: byte offset of a tile's K rows from qkv
+  int* koff = reinterpret_cast<int*>(smem + kAtTabs + 2 * kAtTile * 8);
   int* tind = koff + kAtSpatial + 3;
 
   const int tid = (int)threadIdx.x;
@@ -299,16 +304,15 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
   const int wave = wave_uniform(tid >> 6);
   const int h = lane >> 5, q32 = lane & 31;
 
-  // ---- work-group -> (x, head, window), XCD-aware ---------------------------------------------
-  int L;
-  {
-    const int nwg = k.nwg, id = (int)blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
-    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int bx = L % k.nx;
-  const int head = (L / k.nx) % kHeads;
-  const int win = L / (k.nx * kHeads);
+  // ---- work-group -> (x, head, window), XCD-aware: the hardware deals work-groups to the 8 XCDs round robin
+  // (id & 7); the (window, head) pairs are dealt the same way, so neighbouring (mostly equally masked) windows spread
+  // over all XCDs, and the work-groups of ONE pair follow each other on one XCD: they run together and share its L2.
+  const int xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
+  const int pair = xcd + 8 * (jx / k.nx);
+  const int bx = jx % k.nx;
+  if (pair >= k.npairs) return;
+  const int head = pair & (kHeads - 1);
+  const int win = pair >> 2;
   const int wi = win / k.nww, wj = win - wi * k.nww;
   const int r0 = wi * kWinH, c0 = wj * kWinW;
   const bool masked = k.win_masked[win] != 0;
@@ -355,41 +359,35 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
   }
 
   // ---- copy roles: this wave copies rows 16*wave + 4*jj + (lane >> 4), jj = 0..3, of a tile --------
+  // Row addresses come from a per-tile table in LDS written by wave 0 two tiles ahead (lane = key slot of the tile:
+  // one (key frame, index inside the frame) pair per lane, advancing by 64 per tile with at most one frame wrap since
+  // 45 + 148 > 64); keys past the end alias a valid row (their scores are masked, and 0 x finite = 0).
   const int g16 = lane >> 4, slot = lane & 15;
-  const int64_t frame_elems = (int64_t)k.Hp * k.Wp * (3 * kDim);
+  const int64_t frame_bytes = (int64_t)k.Hp * k.Wp * (3 * kDim) * 2;
   const int per_frame = kAtSpatial + k.npool;
-  const half_t* rowp[4];  // K row of the key (V row = +kDim); nullptr = past the end (zero rows)
-  int kr[4], kfi[4];      // (index inside the key frame, key frame) of the NEXT tile's rows
-  auto resolve = [&](int jj) __attribute__((always_inline)) {
-    const int fi = kfi[jj], r = kr[jj];
-    const int fr = tind[fi < k.nt ? fi : 0];
-    const int ko = koff[r < kAtSpatial ? r : 0];
-    const half_t* sp = k.qkv + (int64_t)fr * frame_elems + ko;
-    const half_t* pp = k.pkv + ((int64_t)fr * k.npool + (r - kAtSpatial)) * (2 * kDim) + head * kHeadDim;
-    const half_t* rp = r < kAtSpatial ? sp : pp;
-    rowp[jj] = fi < k.nt ? rp : nullptr;
-  };
-  auto advance = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      kr[jj] += kAtTile;
-      if (kr[jj] >= per_frame) {
-        kr[jj] -= per_frame;
-        ++kfi[jj];
-      }
-      resolve(jj);
+  const unsigned char* qkv_b = reinterpret_cast<const unsigned char*>(k.qkv);
+  const int64_t pkv_rel = reinterpret_cast<const unsigned char*>(k.pkv) - qkv_b + (int64_t)head * kAtRow;
+  int kr = lane, kfi = 0;  // wave 0: the key this lane resolves next
+  auto produce = [&](int par) __attribute__((always_inline)) {
+    const int fi = kfi < k.nt ? kfi : k.nt - 1;
+    const int fr = tind[fi];
+    const int64_t sp = (int64_t)fr * frame_bytes + (int64_t)koff[kr < kAtSpatial ? kr : 0] * 2;
+    const int64_t pp = pkv_rel + ((int64_t)fr * k.npool + (kr - kAtSpatial)) * (2 * kDim * 2);
+    rowtab[par * kAtTile + lane] = kr < kAtSpatial ? sp : pp;
+    kr += kAtTile;
+    if (kr >= per_frame) {
+      kr -= per_frame;
+      ++kfi;
     }
   };
-  auto issue = [&](auto stage) __attribute__((always_inline)) {  // copy the rows in rowp[] into `stage`
+  auto issue = [&](auto stage, const int64_t* rows) __attribute__((always_inline)) {  // copy the 64 rows `rows[]` into `stage`
     unsigned char* st = smem + decltype(stage)::value * kAtStage;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int rq = 4 * jj + g16;  // row & 15
-      const bool ok = rowp[jj] != nullptr;
-      const void* ks = ok ? static_cast<const void*>(rowp[jj] + ((slot ^ rq) << 3)) : static_cast<const void*>(pp_zero16);
-      const void* vs = ok ? static_cast<const void*>(rowp[jj] + kDim + ((slot ^ (g16 << 2)) << 3)) : static_cast<const void*>(pp_zero16);
-      glds16(ks, st + (16 * wave + 4 * jj) * kAtRow);
-      glds16(vs, st + kAtHalf + (16 * wave + 4 * jj) * kAtRow);
+      const unsigned char* rp = qkv_b + rows[16 * wave + rq];
+      glds16(rp + ((slot ^ rq) << 4), st + (16 * wave + 4 * jj) * kAtRow);
+      glds16(rp + kDim * 2 + ((slot ^ (g16 << 2)) << 4), st + kAtHalf + (16 * wave + 4 * jj) * kAtRow);
     }
   };
 
@@ -443,9 +441,18 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
     for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
     mt = pair32_max(mt);
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = fast_exp2((m_run - m_new) * sc);
-    const float nm = -m_new * sc;
-    m_run = m_new;
+    // the running maximum of most rows stops moving after a few tiles: rescale O and l only when some row of the wave
+    // moved (wave-uniform branch; exact -- nothing is deferred)
+    if (wave_any(m_new > m_run)) {
+      const float alpha = fast_exp2((m_run - m_new) * sc);
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      m_run = m_new;
+    }
+    const float nm = -m_run * sc;
     float ps = 0.f;
     h8 pf[2][2];
 #pragma unroll
@@ -456,11 +463,7 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
         ps += p;
         pf[kb][r >> 3][r & 7] = (half_t)p;
       }
-    l_run = l_run * alpha + ps;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    l_run += ps;
     // four groups (kb, m) of 16 keys: the transposing reads of group g+1 are in flight under the MFMAs of group g
     // (two register sets; the reads are instructions hipcc does not see, see lds_tr16_issue)
     h4 fa[8], fb[8];
@@ -504,44 +507,38 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
   if (masked) {
     const int nk = k.nt * per_frame;
     const int ntiles = (nk + kAtTile - 1) / kAtTile;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      kr[jj] = 16 * wave + 4 * jj + g16;  // < 64 <= per_frame
-      kfi[jj] = 0;
-      resolve(jj);
+    if (wave == 0) {
+      produce(0);
+      produce(1);
     }
-    issue(S0{});
-    advance();
+    __syncthreads();
+    issue(S0{}, rowtab);
     for (int i = 0; i < ntiles; i += 2) {
       pp_wait_vmcnt<0>();
+      pp_wait_lgkm0();
       pp_barrier();
-      if (i + 1 < ntiles) {
-        issue(S1{});
-        advance();
-      }
+      if (i + 1 < ntiles && !((k.dbg & 1) && i > 1)) issue(S1{}, rowtab + kAtTile);
+      if (wave == 0) produce(0);  // rows of tile i+2
       tile(S0{}, nk - i * kAtTile);
       if (i + 1 < ntiles) {
         pp_wait_vmcnt<0>();
+        pp_wait_lgkm0();
         pp_barrier();
-        if (i + 2 < ntiles) {
-          issue(S0{});
-          advance();
-        }
+        if (i + 2 < ntiles && !((k.dbg & 1) && i > 1)) issue(S0{}, rowtab);
+        if (wave == 0) produce(1);  // rows of tile i+3
         tile(S1{}, nk - (i + 1) * kAtTile);
       }
     }
   } else {
     // two frames: frame 2bx -> stage 0, frame 2bx+1 -> stage 1; the 45 own tokens of the frame are the keys
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int fr = 2 * bx + f;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int r = 16 * wave + 4 * jj + g16;
-        rowp[jj] = (fr < k.t && r < kWinTok) ? k.qkv + (int64_t)fr * frame_elems + koff[r < kWinTok ? r : 0] : nullptr;
-      }
-      if (f == 0) issue(S0{}); else issue(S1{});
+    // (rows 45..63 alias token 44, a missing second frame aliases the first: masked / never read)
+    if (wave < 2) {
+      const int fr = 2 * bx + wave < k.t ? 2 * bx + wave : 2 * bx;
+      rowtab[wave * kAtTile + lane] = (int64_t)fr * frame_bytes + (int64_t)koff[lane < kWinTok ? lane : kWinTok - 1] * 2;
     }
+    __syncthreads();
+    issue(S0{}, rowtab);
+    issue(S1{}, rowtab + kAtTile);
     pp_wait_vmcnt<0>();
     pp_barrier();
     if (wave >> 1) tile(S1{}, kWinTok); else tile(S0{}, kWinTok);
@@ -621,10 +618,12 @@ static int launch_window_attention_f16(void* stream, const pp_window_attention_p
   const int nwin = (k.Hp / kWinH) * k.nww;
   const int nqb = (k.t * kWinTok + 127) / 128, npair = (k.t + 1) / 2;
   k.nx = nqb > npair ? nqb : npair;
-  k.nwg = k.nx * kHeads * nwin;
+  k.npairs = kHeads * nwin;
+  k.dbg = getenv("PP_ATTN_DBG") ? atoi(getenv("PP_ATTN_DBG")) : 0;
+  const int nwg = 8 * ((k.npairs + 7) / 8) * k.nx;
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&window_attention_f16_kernel), kAtSmem), true);
   (void)lds_ok;
-  PP_LAUNCH(window_attention_f16_kernel, dim3((unsigned)k.nwg), dim3(256), kAtSmem, stream, k);
+  PP_LAUNCH(window_attention_f16_kernel, dim3((unsigned)nwg), dim3(256), kAtSmem, stream, k);
   return pp_check_launch("pp_window_attention");
 }
 
