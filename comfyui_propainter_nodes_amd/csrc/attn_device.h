@@ -46,6 +46,9 @@ __device__ __forceinline__ float pair32_sum(float v) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+// LDS writes of this wave visible to its other lanes: the hardware executes a wave's LDS operations in order, so only the
+// counter wait is needed; the emulator runs lanes as independent fibers and needs a rendezvous here
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #else
 inline f16v mfma_32x32x16_f16(h8 a, h8 b, f16v c) {
   struct Slot {
@@ -100,6 +103,7 @@ inline float pair32_sum(float v) {
 }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline int wave_uniform(int v) { return v; }
+inline void wave_lds_fence() { pp_emu::wave_sync(); }
 inline bool wave_any(bool p) {
   float f = p ? 1.f : 0.f;
   for (int m = 1; m < 64; m <<= 1) f = fmaxf(f, shfl_xor(f, m));

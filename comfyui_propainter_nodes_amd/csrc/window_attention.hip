@@ -7,7 +7,7 @@
 #include "attn_device.h"
 #include "pp_host.h"
 
-#include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 namespace pp {
@@ -249,25 +249,31 @@ __global__ void __launch_bounds__(256) window_attention_generic_kernel(const Att
 // f16 kernel (r03)
 //
 // Work-group = 4 waves; a wave owns 32 queries of one (window, head).  Masked window: the work-group is a 128-query
-// block of the window's 45*t queries and walks all nt * (45 + 148 + npool) keys in 64-key tiles; unmasked window: the
-// work-group handles two frames (waves 0,1 / 2,3), one 64-key tile (45 valid keys) each.
+// block of the window's 45*t queries and walks all nt * (45 + 148 + npool) keys in 32-key tiles; unmasked window: the
+// work-group handles two frames (waves 0,1 / 2,3), two tiles (45 valid keys) each.
 //   tiles     K and V rows (256 B each) are copied global -> LDS by global_load_lds (16 B per lane, 4 rows per wave
-//             instruction), tile i+1 in flight while tile i is consumed; ONE barrier per tile.  The LDS image of a
-//             tile is [64 rows][16 slots of 16 B]; the slot permutation is applied to the SOURCE address of the copy:
+//             instruction) into two 4-slot rings (8 KB per slot): K three-to-four tiles ahead of its use, V three --
+//             one tile of compute hides ~1/3 of the copy latency, measured r03 with a 2-stage ring: 20 % of the kernel
+//             time was the wait for the copy issued one tile earlier.  ONE barrier per tile.  The LDS image of a tile is
+//             [32 rows][16 slots of 16 B]; the slot permutation is applied to the SOURCE address of the copy:
 //               K: slot = chunk ^ (row & 15)        -> the ds_read_b128 fragment reads (32 rows, one chunk) are conflict-free
 //               V: slot = chunk ^ ((row & 3) << 2)  -> the transposing reads (4 rows x 64 B per half-wave) are conflict-free
+//             (SQ_LDS_BANK_CONFLICT = 0.04 % of SQ_LDS_IDX_ACTIVE, profiles/r03_attention_counters.md)
 //   S^T       = K . Q^T on v_mfma_f32_32x32x16_f16 (A = K rows from LDS, B = Q fragments in registers): lane (h, q)
-//             holds, for query q = lane & 31, the scores of keys 32*kb + (r&3) + 8*(r>>2) + 4*h, r = 0..15, kb = 0,1;
-//   softmax   online, lane-local over its 32 scores + one v_permlane32_swap for the row maximum; the row sum stays
-//             split over the two half-waves until the end;
-//   O^T      += V^T . P^T: B = the lane's own probabilities (registers 8m..8m+7 of S[kb] as f16: keys 16m+4h+{0..3} and
+//             holds, for query q = lane & 31, the scores of keys (r&3) + 8*(r>>2) + 4*h, r = 0..15, of the tile;
+//   softmax   online, lane-local over its 16 scores + one v_permlane32_swap for the row maximum; the row sum stays
+//             split over the two half-waves until the end; O / l are rescaled only when some row maximum of the wave
+//             moved (wave-uniform branch, exact);
+//   O^T      += V^T . P^T: B = the lane's own probabilities (registers 8m..8m+7 of S as f16: keys 16m+4h+{0..3} and
 //             16m+8+4h+{0..3}), A = two ds_read_b64_tr_b16 of the row-major V tile in the same key order -- the
 //             probabilities never leave registers and V is never transposed in memory.
+//   pipeline  S^T of tile i+1 is issued BEFORE the softmax of tile i (its 8 MFMAs run under the exponentials of tile i),
+//             then O^T += of tile i: inside one wave the matrix pipe and the vector ALU overlap; the second wave of the
+//             SIMD (another work-group: 2 per CU) fills the rest.
 // Key addressing: per work-group tables in LDS (spatial offset of the 193 own + rolled-neighbour tokens, the frames of
-// t_ind); a lane's four key rows advance by 64 per tile with at most one frame wrap (45 + 148 > 64).
-// Work-group -> (query block, head, window) mapping is XCD-aware: the blocks that share a key set are neighbours in
-// the linear order of ONE XCD, so the key set is fetched into one L2 (r02: every 128-query block re-fetched it through
-// whichever of the 8 L2s it landed on: 2.3x the algorithmic traffic).
+// t_ind); lanes 0..7 of a wave resolve the wave's 8 rows of a tile five tiles ahead into a wave-private row table (one
+// (key frame, index in the frame) pair per lane, advancing by 32 per tile: at most one frame wrap since 45 + 148 > 32).
+// Work-group -> (query block, head, window) mapping is XCD-aware, see the kernel.
 // ----------------------------------------------------------------------------------------
 struct AttnF16K {
   const half_t* qkv;
@@ -278,31 +284,38 @@ struct AttnF16K {
   int t, nt, Hp, Wp, fh, fw, npool, nww;
   int nx;        // work-groups per (head, window): max(128-query blocks of a masked window, frame pairs)
   int npairs;    // (window, head) pairs
-  int dbg;
+#ifdef PP_ATTN_TRACE
+  long long* trace;  // tools/trace_attention.sh: [0] claim flag, [1] steps, then 8 time stamps per step of two waves
+#endif
   float scale_log2e;
   signed char nb[148 * 2];
 };
 
-constexpr int kAtTile = 64;                     // keys per tile
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+constexpr int kAtTile = 32;                     // keys per tile
 constexpr int kAtRow = kHeadDim * 2;            // bytes per key row
-constexpr int kAtHalf = kAtTile * kAtRow;       // K (or V) bytes per stage
-constexpr int kAtStage = 2 * kAtHalf;           // K | V
+constexpr int kAtSlot = kAtTile * kAtRow;       // bytes per ring slot (8 KB)
+constexpr int kAtRing = 4;                      // slots per ring
+constexpr int kAtVBase = kAtRing * kAtSlot;     // V ring behind the K ring
 constexpr int kAtSpatial = kWinTok + 148;       // own + rolled-neighbour tokens per key frame
 constexpr int kAtMaxNt = 1024;
-constexpr int kAtTabs = 2 * kAtStage;                                  // [rowtab 2 x 64 x i64][koff][tind]
-constexpr int kAtSmem = kAtTabs + 2 * kAtTile * 8 + (kAtSpatial + 3 + kAtMaxNt) * 4;
+constexpr int kAtTabs = 2 * kAtRing * kAtSlot;  // [rowtab: 4 waves x 16 tiles x 8 rows x i64][koff][tind]
+constexpr int kAtRowTab = 4 * 16 * 8 * 8;
+constexpr float kAtDefer = 8.f;  // rescale O / l only when a row maximum grew by more than 2^8 (see softmax_head)
+constexpr int kAtSmem = kAtTabs + kAtRowTab + (kAtSpatial + 3 + kAtMaxNt) * 4;
 static_assert(kHeads == 4, "pair decoding");
 
 __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const AttnF16K k) {
-  unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);  // [stage 0: K | V][stage 1: K | V][rowtab][koff][tind]
-  int64_t* rowtab = reinterpret_cast<int64_t*>(smem + kAtTabs);         // [2][64]: byte offset of a tile's K rows from qkv
-  int* koff = reinterpret_cast<int*>(smem + kAtTabs + 2 * kAtTile * 8);
+  unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);  // [K ring][V ring][rowtab][koff][tind]
+  int* koff = reinterpret_cast<int*>(smem + kAtTabs + kAtRowTab);
   int* tind = koff + kAtSpatial + 3;
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = wave_uniform(tid >> 6);
   const int h = lane >> 5, q32 = lane & 31;
+  int64_t* rowtab = reinterpret_cast<int64_t*>(smem + kAtTabs) + wave * 128;  // this wave's [16 tiles][8 rows]
 
   // ---- work-group -> (x, head, window), XCD-aware: the hardware deals work-groups to the 8 XCDs round robin
   // (id & 7); the (window, head) pairs are dealt the same way, so neighbouring (mostly equally masked) windows spread
@@ -358,41 +371,55 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
     for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const h8*>(qptr + 16 * c);
   }
 
-  // ---- copy roles: this wave copies rows 16*wave + 4*jj + (lane >> 4), jj = 0..3, of a tile --------
-  // Row addresses come from a per-tile table in LDS written by wave 0 two tiles ahead (lane = key slot of the tile:
-  // one (key frame, index inside the frame) pair per lane, advancing by 64 per tile with at most one frame wrap since
-  // 45 + 148 > 64); keys past the end alias a valid row (their scores are masked, and 0 x finite = 0).
+  // ---- copy roles: this wave copies rows 8*wave + 4*jj + (lane >> 4), jj = 0,1, of a tile ----------------
+  // keys past the end alias a valid row (their scores are masked, and 0 x finite = 0)
   const int g16 = lane >> 4, slot = lane & 15;
   const int64_t frame_bytes = (int64_t)k.Hp * k.Wp * (3 * kDim) * 2;
   const int per_frame = kAtSpatial + k.npool;
   const unsigned char* qkv_b = reinterpret_cast<const unsigned char*>(k.qkv);
   const int64_t pkv_rel = reinterpret_cast<const unsigned char*>(k.pkv) - qkv_b + (int64_t)head * kAtRow;
-  int kr = lane, kfi = 0;  // wave 0: the key this lane resolves next
-  auto produce = [&](int par) __attribute__((always_inline)) {
-    const int fi = kfi < k.nt ? kfi : k.nt - 1;
-    const int fr = tind[fi];
-    const int64_t sp = (int64_t)fr * frame_bytes + (int64_t)koff[kr < kAtSpatial ? kr : 0] * 2;
-    const int64_t pp = pkv_rel + ((int64_t)fr * k.npool + (kr - kAtSpatial)) * (2 * kDim * 2);
-    rowtab[par * kAtTile + lane] = kr < kAtSpatial ? sp : pp;
-    kr += kAtTile;
-    if (kr >= per_frame) {
-      kr -= per_frame;
-      ++kfi;
-    }
-  };
-  auto issue = [&](auto stage, const int64_t* rows) __attribute__((always_inline)) {  // copy the 64 rows `rows[]` into `stage`
-    unsigned char* st = smem + decltype(stage)::value * kAtStage;
+  // Row addresses: every 8 steps a wave resolves its 8 rows of the next 8 tiles with all 64 lanes (lane = (tile, row):
+  // one (key frame, index in the frame) pair per lane, advancing by 256 keys per call) into a wave-private table of 16
+  // tiles; the two row offsets a lane copies are fetched from it one step before the copy is issued (a wave issues in
+  // order: an LDS read followed at once by its use stalls the MFMAs queued behind it for the LDS latency); V of a tile is
+  // copied one step after its K and reuses the registers.
+  int kr = (lane >> 3) * kAtTile + 8 * wave + (lane & 7), kfi = 0;
+  auto resolve_group = [&](int group) __attribute__((always_inline)) {  // tiles 8*group .. 8*group+7
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int rq = 4 * jj + g16;  // row & 15
-      const unsigned char* rp = qkv_b + rows[16 * wave + rq];
-      glds16(rp + ((slot ^ rq) << 4), st + (16 * wave + 4 * jj) * kAtRow);
-      glds16(rp + kDim * 2 + ((slot ^ (g16 << 2)) << 4), st + kAtHalf + (16 * wave + 4 * jj) * kAtRow);
-    }
+    for (int rep = 0; rep < 2; ++rep)  // 256 keys per call, a key frame has at least 193
+      if (kr >= per_frame) {
+        kr -= per_frame;
+        ++kfi;
+      }
+    const int fr = tind[kfi < k.nt ? kfi : k.nt - 1];  // past the end: alias the last frame (masked keys)
+    const int64_t sp = (int64_t)fr * frame_bytes + (int64_t)koff[kr < kAtSpatial ? kr : 0] * 2;
+    const int64_t pl = pkv_rel + ((int64_t)fr * k.npool + (kr - kAtSpatial)) * (2 * kDim * 2);
+    rowtab[((8 * group + (lane >> 3)) & 15) * 8 + (lane & 7)] = kr < kAtSpatial ? sp : pl;
+    kr += 8 * kAtTile;
+  };
+  // wave-uniform parts of the swizzles: row & 15 = (8*wave + 4*jj + g16) & 15, row & 3 = g16
+  const int rq0 = (8 * wave + g16) & 15, rq1 = (8 * wave + 4 + g16) & 15;
+  const int kch0 = (slot ^ rq0) << 4, kch1 = (slot ^ rq1) << 4, vch = kDim * 2 + ((slot ^ (g16 << 2)) << 4);
+  struct Rows {
+    int64_t a, b;
+  };
+  auto fetch_rows = [&](int tile) __attribute__((always_inline)) -> Rows {
+    const int64_t* rows = rowtab + (tile & 15) * 8;
+    return Rows{rows[g16], rows[4 + g16]};
+  };
+  auto issue_k = [&](auto ring_slot, const Rows& r) __attribute__((always_inline)) {
+    unsigned char* st = smem + decltype(ring_slot)::value * kAtSlot + 8 * wave * kAtRow;
+    glds16(qkv_b + r.a + kch0, st);
+    glds16(qkv_b + r.b + kch1, st + 4 * kAtRow);
+  };
+  auto issue_v = [&](auto ring_slot, const Rows& r) __attribute__((always_inline)) {
+    unsigned char* st = smem + kAtVBase + decltype(ring_slot)::value * kAtSlot + 8 * wave * kAtRow;
+    glds16(qkv_b + r.a + vch, st);
+    glds16(qkv_b + r.b + vch, st + 4 * kAtRow);
   };
 
   // ---- fragment offsets -----------------------------------------------------------------------------
-  int kfo[8];  // K fragment: row q32 (+32 for the second key block), chunk 2c + h
+  int kfo[8];  // K fragment: row q32, chunk 2c + h
 #pragma unroll
   for (int c = 0; c < 8; ++c) kfo[c] = q32 * kAtRow + (((2 * c + h) ^ (q32 & 15)) << 4);
   int vfo[4];  // V fragment of d block `db`: rows 4h + (i >> 2), columns 32 db + 16 (g16 & 1) + 4 (i & 3)
@@ -400,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
     const int i = lane & 15, ir = i >> 2;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
-      vfo[db] = kAtHalf + (4 * h + ir) * kAtRow + ((4 * (db ^ ir) + 2 * (g16 & 1) + ((i & 3) >> 1)) << 4) + (i & 1) * 8;
+      vfo[db] = kAtVBase + (4 * h + ir) * kAtRow + ((4 * (db ^ ir) + 2 * (g16 & 1) + ((i & 3) >> 1)) << 4) + (i & 1) * 8;
   }
 
   f16v o[4];
@@ -410,40 +437,55 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
   const float sc = k.scale_log2e;
+#ifdef PP_ATTN_TRACE
+  __shared__ int traced;
+  if (tid == 0) traced = masked && bx == 1 && atomicCAS(reinterpret_cast<unsigned long long*>(k.trace), 0ull, 1ull) == 0ull;
+  __syncthreads();
+  const bool tr_on = traced && (wave == 0 || wave == 3) && lane == 0;
+#define PP_TR(step, slot)                                                                                  \
+  if (tr_on && (step) < 100) k.trace[2 + (((wave ? 1 : 0) * 100 + (step)) * 8) + (slot)] = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define PP_TR(step, slot)
+#endif
 
-  // one 64-key tile in `stage`; keys >= nvalid (counted from the tile start) are masked out
-  auto tile = [&](auto stage, int nvalid) __attribute__((always_inline)) {
-    const unsigned char* st = smem + decltype(stage)::value * kAtStage;
-    f16v s[2];
+  // S^T of the 32-key tile in K ring slot `ring_slot`: the 8 fragment reads are issued early (kfrags, right after the
+  // barrier that publishes the tile) so that their LDS latency passes under the copy issue and the row maxima
+  struct KFrags {
+    h8 f[8];
+  };
+  auto kfrags = [&](auto ring_slot) __attribute__((always_inline)) -> KFrags {
+    const unsigned char* st = smem + decltype(ring_slot)::value * kAtSlot;
+    KFrags r;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int c = 0; c < 8; ++c) r.f[c] = *reinterpret_cast<const h8*>(st + kfo[c]);
+    return r;
+  };
+  auto qk = [&](const KFrags& kf) __attribute__((always_inline)) -> f16v {
+    f16v s;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < 8; ++c) s = mfma_32x32x16_f16(kf.f[c], qf[c], s);
+    return s;
+  };
+  // online softmax, part 1: row maxima of one tile's scores (keys >= nvalid masked out when TAIL)
+  auto softmax_head = [&](f16v& s, auto tail, int nvalid) __attribute__((always_inline)) {
+    if constexpr (decltype(tail)::value) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const h8 a = *reinterpret_cast<const h8*>(st + kfo[c] + kb * 32 * kAtRow);
-        s[kb] = mfma_32x32x16_f16(a, qf[c], s[kb]);
-      }
+      for (int r = 0; r < 16; ++r)
+        if ((r & 3) + 8 * (r >> 2) + 4 * h >= nvalid) s[r] = -1.0e30f;
     }
-    if (nvalid < kAtTile) {
+    float mt = s[0];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= nvalid) s[kb][r] = -1.0e30f;
-    }
-    float mt = s[0][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
     mt = pair32_max(mt);
+    // Deferred rescale: O and l are rescaled (and the reference maximum moved) only when some row maximum of the wave grew
+    // by more than 2^kAtDefer in the exponent; otherwise the probabilities of this tile are taken against the OLD
+    // reference and may reach 2^8 -- exact in f16 / fp32 arithmetic up to rounding (f16 keeps 11 significant bits at any
+    // magnitude, 2^8 x 32 keys is far from its range limit), and O / l are normalised by the same reference at the end.
+    // The decision covers the whole tile before any of its probabilities exists, so nothing is scaled twice or not at all.
     const float m_new = fmaxf(m_run, mt);
-    // the running maximum of most rows stops moving after a few tiles: rescale O and l only when some row of the wave
-    // moved (wave-uniform branch; exact -- nothing is deferred)
-    if (wave_any(m_new > m_run)) {
+    if (wave_any((m_new - m_run) * sc > kAtDefer)) {
       const float alpha = fast_exp2((m_run - m_new) * sc);
       l_run *= alpha;
 #pragma unroll
@@ -452,96 +494,151 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       m_run = m_new;
     }
+  };
+  // part 2: probabilities, then O^T += V^T . P^T from V ring slot `ring_slot` (branch-free: one basic block together
+  // with the S^T MFMAs of the next tile issued in front of it, so the exponentials run under those MFMAs)
+  auto exp_pv = [&](const f16v& s, auto ring_slot) __attribute__((always_inline)) {
     const float nm = -m_run * sc;
     float ps = 0.f;
-    h8 pf[2][2];
+    h8 pf[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(__builtin_fmaf(s[kb][r], sc, nm));
-        ps += p;
-        pf[kb][r >> 3][r & 7] = (half_t)p;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float p = fast_exp2(__builtin_fmaf(s[r], sc, nm));
+      ps += p;
+      pf[r >> 3][r & 7] = (half_t)p;
+    }
     l_run += ps;
-    // four groups (kb, m) of 16 keys: the transposing reads of group g+1 are in flight under the MFMAs of group g
-    // (two register sets; the reads are instructions hipcc does not see, see lds_tr16_issue)
+    // two groups of 16 keys: the transposing reads are instructions hipcc does not see (lds_tr16_issue)
     h4 fa[8], fb[8];
     constexpr int kKeyOff = 8 * kAtRow;
-    auto vissue = [&](auto grp, h4* f) __attribute__((always_inline)) {
-      constexpr int G = decltype(grp)::value;
-      constexpr int base = decltype(stage)::value * kAtStage + ((G >> 1) * 32 + 16 * (G & 1)) * kAtRow;
-      lds_tr16_issue<base>(f[0], smem + vfo[0]);
-      lds_tr16_issue<base + kKeyOff>(f[1], smem + vfo[0]);
-      lds_tr16_issue<base>(f[2], smem + vfo[1]);
-      lds_tr16_issue<base + kKeyOff>(f[3], smem + vfo[1]);
-      lds_tr16_issue<base>(f[4], smem + vfo[2]);
-      lds_tr16_issue<base + kKeyOff>(f[5], smem + vfo[2]);
-      lds_tr16_issue<base>(f[6], smem + vfo[3]);
-      lds_tr16_issue<base + kKeyOff>(f[7], smem + vfo[3]);
+    constexpr int base = decltype(ring_slot)::value * kAtSlot;
+    auto vissue = [&](auto off, h4* f) __attribute__((always_inline)) {
+      constexpr int B = base + decltype(off)::value;
+      lds_tr16_issue<B>(f[0], smem + vfo[0]);
+      lds_tr16_issue<B + kKeyOff>(f[1], smem + vfo[0]);
+      lds_tr16_issue<B>(f[2], smem + vfo[1]);
+      lds_tr16_issue<B + kKeyOff>(f[3], smem + vfo[1]);
+      lds_tr16_issue<B>(f[4], smem + vfo[2]);
+      lds_tr16_issue<B + kKeyOff>(f[5], smem + vfo[2]);
+      lds_tr16_issue<B>(f[6], smem + vfo[3]);
+      lds_tr16_issue<B + kKeyOff>(f[7], smem + vfo[3]);
     };
-    auto vmfma = [&](int kb, int m, h4* f) __attribute__((always_inline)) {
+    auto vmfma = [&](int m, h4* f) __attribute__((always_inline)) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         const h4 lo = f[2 * db], hi = f[2 * db + 1];
         const h8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        o[db] = mfma_32x32x16_f16(a, pf[kb][m], o[db]);
+        o[db] = mfma_32x32x16_f16(a, pf[m], o[db]);
       }
     };
     vissue(std::integral_constant<int, 0>{}, fa);
-    vissue(std::integral_constant<int, 1>{}, fb);
+    vissue(std::integral_constant<int, 16 * kAtRow>{}, fb);
     lds_tr16_wait<8>(fa[0], fa[1], fa[2], fa[3], fa[4], fa[5], fa[6], fa[7]);
-    vmfma(0, 0, fa);
-    vissue(std::integral_constant<int, 2>{}, fa);
-    lds_tr16_wait<8>(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], fb[7]);
-    vmfma(0, 1, fb);
-    vissue(std::integral_constant<int, 3>{}, fb);
-    lds_tr16_wait<8>(fa[0], fa[1], fa[2], fa[3], fa[4], fa[5], fa[6], fa[7]);
-    vmfma(1, 0, fa);
+    vmfma(0, fa);
     lds_tr16_wait<0>(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], fb[7]);
-    vmfma(1, 1, fb);
+    vmfma(1, fb);
   };
-  typedef std::integral_constant<int, 0> S0;
-  typedef std::integral_constant<int, 1> S1;
+  typedef std::false_type NoTail;
+  typedef std::true_type Tail;
+  typedef std::integral_constant<int, 0> R0;
+  typedef std::integral_constant<int, 1> R1;
+  typedef std::integral_constant<int, 2> R2;
+  typedef std::integral_constant<int, 3> R3;
 
   if (masked) {
     const int nk = k.nt * per_frame;
     const int ntiles = (nk + kAtTile - 1) / kAtTile;
-    if (wave == 0) {
-      produce(0);
-      produce(1);
-    }
-    __syncthreads();
-    issue(S0{}, rowtab);
-    for (int i = 0; i < ntiles; i += 2) {
-      pp_wait_vmcnt<0>();
-      pp_wait_lgkm0();
+    const int last = ntiles - 1;
+    // copies are issued in a fixed pattern -- per step: V of tile s+3, K of tile s+4 (tiles past the end resolve to
+    // aliases of valid rows: uniform instruction counts keep the vmcnt arithmetic simple; the slots they land in are
+    // never read)
+    resolve_group(0);
+    wave_lds_fence();
+    Rows rv, rk;
+    rk = fetch_rows(0);
+    issue_k(R0{}, rk);                          // step -4
+    rv = rk; rk = fetch_rows(1);
+    issue_v(R0{}, rv); issue_k(R1{}, rk);       // step -3
+    rv = rk; rk = fetch_rows(2);
+    issue_v(R1{}, rv); issue_k(R2{}, rk);       // step -2
+    rv = rk; rk = fetch_rows(3);
+    issue_v(R2{}, rv); issue_k(R3{}, rk);       // step -1
+    rv = rk; rk = fetch_rows(4);                // for step 0
+    pp_wait_vmcnt<12>();                        // K of tile 0 has landed (this wave's rows)
+    pp_barrier();
+    f16v s_cur = qk(kfrags(R0{}));
+    // step i (ring position P = i & 3): V(i) and K(i+1) have landed; issue V(i+3) -> V slot (P+3)&3 and K(i+4) -> K slot P
+    // (both read for the last time in step i-1); S^T(i+1) from K slot (P+1)&3, softmax(i), O^T += from V slot P
+    auto step = [&](int i, auto P, auto P1, auto P3) __attribute__((always_inline)) {
+      PP_TR(i, 0);
+      pp_wait_vmcnt<8>();
+      PP_TR(i, 1);
       pp_barrier();
-      if (i + 1 < ntiles && !((k.dbg & 1) && i > 1)) issue(S1{}, rowtab + kAtTile);
-      if (wave == 0) produce(0);  // rows of tile i+2
-      tile(S0{}, nk - i * kAtTile);
-      if (i + 1 < ntiles) {
-        pp_wait_vmcnt<0>();
-        pp_wait_lgkm0();
-        pp_barrier();
-        if (i + 2 < ntiles && !((k.dbg & 1) && i > 1)) issue(S0{}, rowtab);
-        if (wave == 0) produce(1);  // rows of tile i+3
-        tile(S1{}, nk - (i + 1) * kAtTile);
-      }
+      PP_TR(i, 2);
+      const KFrags kf = kfrags(P1);
+      issue_v(P3, rv);
+      issue_k(P, rk);
+      rv = rk;
+      rk = fetch_rows(i + 5);
+      if (decltype(P)::value == 0 && (i & 7) == 0) resolve_group((i >> 3) + 1);  // first read in step i + 3
+      PP_TR(i, 3);
+      softmax_head(s_cur, NoTail{}, kAtTile);
+      PP_TR(i, 4);
+      const f16v s_next = qk(kf);
+      exp_pv(s_cur, P);
+      s_cur = s_next;
+      PP_TR(i, 5);
+    };
+    auto final_step = [&](auto P) __attribute__((always_inline)) {  // the last tile: masked tail, nothing left to copy
+      pp_wait_vmcnt<0>();
+      pp_barrier();
+      softmax_head(s_cur, Tail{}, nk - last * kAtTile);
+      exp_pv(s_cur, P);
+    };
+    int i = 0;
+    for (; i + 4 <= last; i += 4) {
+      step(i, R0{}, R1{}, R3{});
+      step(i + 1, R1{}, R2{}, R0{});
+      step(i + 2, R2{}, R3{}, R1{});
+      step(i + 3, R3{}, R0{}, R2{});
     }
+    const int rem = last - i;  // 0..3 full tiles, then the last one at ring position rem
+    if (rem > 0) step(i, R0{}, R1{}, R3{});
+    if (rem > 1) step(i + 1, R1{}, R2{}, R0{});
+    if (rem > 2) step(i + 2, R2{}, R3{}, R1{});
+    if (rem == 0) final_step(R0{});
+    else if (rem == 1) final_step(R1{});
+    else if (rem == 2) final_step(R2{});
+    else final_step(R3{});
   } else {
-    // two frames: frame 2bx -> stage 0, frame 2bx+1 -> stage 1; the 45 own tokens of the frame are the keys
-    // (rows 45..63 alias token 44, a missing second frame aliases the first: masked / never read)
-    if (wave < 2) {
-      const int fr = 2 * bx + wave < k.t ? 2 * bx + wave : 2 * bx;
-      rowtab[wave * kAtTile + lane] = (int64_t)fr * frame_bytes + (int64_t)koff[lane < kWinTok ? lane : kWinTok - 1] * 2;
+    // two frames: waves 0,1 -> frame 2bx (ring slots 0,1), waves 2,3 -> frame 2bx+1 (slots 2,3); keys = the 45 own
+    // tokens of the frame as two tiles (rows past 44 alias token 44, a missing second frame aliases the first: masked /
+    // never read).  Every wave copies its 8 rows of all four slots.
+    const int f1 = 2 * bx + 1 < k.t ? 2 * bx + 1 : 2 * bx;
+    if (lane < 8) {
+      const int ra = 8 * wave + lane, rb = 32 + 8 * wave + lane;
+      rowtab[0 * 8 + lane] = (int64_t)(2 * bx) * frame_bytes + (int64_t)koff[ra] * 2;
+      rowtab[1 * 8 + lane] = (int64_t)(2 * bx) * frame_bytes + (int64_t)koff[rb < kWinTok ? rb : kWinTok - 1] * 2;
+      rowtab[2 * 8 + lane] = (int64_t)f1 * frame_bytes + (int64_t)koff[ra] * 2;
+      rowtab[3 * 8 + lane] = (int64_t)f1 * frame_bytes + (int64_t)koff[rb < kWinTok ? rb : kWinTok - 1] * 2;
     }
-    __syncthreads();
-    issue(S0{}, rowtab);
-    issue(S1{}, rowtab + kAtTile);
+    wave_lds_fence();
+    const Rows u0 = fetch_rows(0), u1 = fetch_rows(1), u2 = fetch_rows(2), u3 = fetch_rows(3);
+    issue_k(R0{}, u0); issue_v(R0{}, u0);
+    issue_k(R1{}, u1); issue_v(R1{}, u1);
+    issue_k(R2{}, u2); issue_v(R2{}, u2);
+    issue_k(R3{}, u3); issue_v(R3{}, u3);
     pp_wait_vmcnt<0>();
     pp_barrier();
-    if (wave >> 1) tile(S1{}, kWinTok); else tile(S0{}, kWinTok);
+    auto frame = [&](auto A, auto B) __attribute__((always_inline)) {
+      f16v s = qk(kfrags(A));
+      softmax_head(s, NoTail{}, kAtTile);
+      exp_pv(s, A);
+      s = qk(kfrags(B));
+      softmax_head(s, Tail{}, kWinTok - kAtTile);
+      exp_pv(s, B);
+    };
+    if (wave >> 1) frame(R2{}, R3{}); else frame(R0{}, R1{});
   }
 
   // ---- normalise and scatter back to the unpadded token grid -------------------------------------
@@ -619,11 +716,49 @@ static int launch_window_attention_f16(void* stream, const pp_window_attention_p
   const int nqb = (k.t * kWinTok + 127) / 128, npair = (k.t + 1) / 2;
   k.nx = nqb > npair ? nqb : npair;
   k.npairs = kHeads * nwin;
-  k.dbg = getenv("PP_ATTN_DBG") ? atoi(getenv("PP_ATTN_DBG")) : 0;
   const int nwg = 8 * ((k.npairs + 7) / 8) * k.nx;
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&window_attention_f16_kernel), kAtSmem), true);
   (void)lds_ok;
+#ifdef PP_ATTN_TRACE
+  static long long* trace = nullptr;
+  const size_t tbytes = (2 + 2 * 100 * 8) * sizeof(long long);
+  if (!trace) hipMalloc(&trace, tbytes);
+  hipMemsetAsync(trace, 0, tbytes, (hipStream_t)stream);
+  k.trace = trace;
+#endif
   PP_LAUNCH(window_attention_f16_kernel, dim3((unsigned)nwg), dim3(256), kAtSmem, stream, k);
+#ifdef PP_ATTN_TRACE
+  {
+    static long long host[2 + 2 * 100 * 8];
+    hipMemcpyAsync(host, trace, tbytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    hipStreamSynchronize((hipStream_t)stream);
+    static int dumped = 0;
+    if (dumped++ == 3) {  // one warmed-up launch
+      const char* names[6] = {"top", "vmcnt", "barrier", "issue+resolve", "head", "qk+exp+pv"};
+      for (int w = 0; w < 2; ++w) {
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        int n = 0;
+        for (int st = 4; st < 76; ++st) {
+          const long long* t = host + 2 + (w * 100 + st) * 8;
+          const long long* tn = host + 2 + (w * 100 + st + 1) * 8;
+          if (!t[0] || !tn[0]) continue;
+          for (int j = 0; j < 5; ++j) sum[j + 1] += (double)(t[j + 1] - t[j]);
+          sum[0] += (double)(tn[0] - t[0]);
+          ++n;
+        }
+        fprintf(stderr, "attention trace wave %d (%d steps): step %.0f clk =", w ? 3 : 0, n, n ? sum[0] / n : 0.0);
+        for (int j = 1; j < 6; ++j) fprintf(stderr, " %s %.0f |", names[j], n ? sum[j] / n : 0.0);
+        fprintf(stderr, "\n");
+        for (int st = 20; st < 26; ++st) {
+          const long long* t = host + 2 + (w * 100 + st) * 8;
+          fprintf(stderr, "   step %d:", st);
+          for (int j = 0; j < 5; ++j) fprintf(stderr, " %lld", t[j + 1] - t[j]);
+          fprintf(stderr, "  -> next %lld\n", host[2 + (w * 100 + st + 1) * 8] - t[0]);
+        }
+      }
+    }
+  }
+#endif
   return pp_check_launch("pp_window_attention");
 }
 

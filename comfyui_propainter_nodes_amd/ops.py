@@ -459,7 +459,13 @@ def corr_lookup(pyramid: list[torch.Tensor], flow: torch.Tensor, out: torch.Tens
     P.flow, P.flow_ldc = flow.data_ptr(), fl
     P.out, P.out_ldc = out.data_ptr(), nhwc_view(out)[4]
     P.N, P.h, P.w = n, h, w
-    _call("pp_corr_lookup", out, P)
+    if CONV_PROFILE is not None and out.is_cuda:
+        # algorithmic bytes: per pixel the 10x10 fp32 footprint of the 9x9 bilinear samples on each level
+        # + the 324 fp32 outputs
+        nbytes = float(n * h * w) * (len(pyramid) * 100 * 4 + 324 * 4)
+        CONV_PROFILE.launch("corr_lookup", 0.0, lambda: _call("pp_corr_lookup", out, P), nbytes)
+    else:
+        _call("pp_corr_lookup", out, P)
     return out
 
 
@@ -684,7 +690,17 @@ def window_attention(qkv: torch.Tensor, pkv: torch.Tensor, win_masked: torch.Ten
     P.dtype = dtype_code(qkv.dtype)
     P.t, P.nt, P.Hp, P.Wp, P.fh, P.fw, P.npool = t, t_ind.numel(), hp, wp, fh, fw, pkv.shape[1]
     P.scale = 1.0 / (128 ** 0.5)
-    _call("pp_window_attention", out, P)
+    if CONV_PROFILE is not None and out.is_cuda:
+        # algorithmic work: masked window = 45 t queries x nt (45 + 148 + npool) keys per head, unmasked = 45 x 45 per
+        # frame and head; 4 flops per (query, key, channel).  (the masked-window count is read back: profiling only)
+        nwin = win_masked.numel()
+        nm = int(win_masked.ne(0).sum())
+        nk = t_ind.numel() * (45 + 148 + pkv.shape[1])
+        flops = 4.0 * 128 * 4 * (nm * 45.0 * t * nk + (nwin - nm) * t * 45.0 * 45.0)
+        nbytes = float(qkv.numel() + pkv.numel() + out.numel()) * qkv.element_size()
+        CONV_PROFILE.launch("attention", flops, lambda: _call("pp_window_attention", out, P), nbytes)
+    else:
+        _call("pp_window_attention", out, P)
     return out
 
 

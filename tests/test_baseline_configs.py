@@ -6,6 +6,10 @@ Fixtures (tests/golden/cfg*_node.npz) were minted by running the reference's own
   cfg1_node      BASELINE configs[0]: 16 frames 320x180 -> 320x176 (PIL bicubic resize path), raft_iter 5
   cfg2_24f_node  configs[1] geometry: 640x360, nl 10, rs 10, raft_iter 20 (30x54 tokens, 6x6 windows), 24-frame truncation
   cfg3_12f_node  configs[2] geometry: outpaint 640x360 -> 768x360, 12-frame truncation
+  cfg2_80f_node  configs[1] IN FULL (r03): the 80-frame clip bench.py times
+  cfg4_100f_node configs[3]'s mode at its size (r03): 100 frames > subvideo_length 80 -> local reference frames (ref_num 8),
+                 flow completion in two sub-videos with 5-frame halos, image propagation with 10-frame halos
+  mov_20f_node   per-frame (moving) MASK input (r03): mask.shape[0] == T, one dilation per mask frame
 Tolerances (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact):
   RAFT flows 2e-3 px; updated masks <= 0.5 % differing pixels; final uint8 frames: exactly the input outside the dilated
   mask, PSNR >= 40 dB and >= 99 % within 2 LSB inside it; node mask outputs bit-exact.
@@ -19,6 +23,13 @@ Tolerances (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact
   5e-4 px at 16 frames of 320x176, 6e-2 / 2e-2 / 2e-3 at 12 frames of 768x360, 1.4 / 0.55 / 1.6e-2 at 24 frames of
   640x360 -- so that mode only asserts mean < 5e-2 px and max < 3 px on the stage and relies on the fp32 mode for the
   tight stage check; the final-frame bound is the same in both modes.
+  Clips of more than 40 frames (r03: the full 80-frame configs[1], the 100-frame long-clip case): INSIDE the hole the
+  recurrence is chaotic with these weights -- the reference's own fp32 arithmetic (the CPU oracle) fed with our RAFT flows
+  (1.4e-4 px from the reference's) lands 3.9 px max / 5e-2 mean from the reference's result, exactly where our fp32 and f16
+  runs land (3.8 / 4.1 px), while the stage agrees to 1e-5 px with the oracle on identical input where the recurrence is
+  stable (tests/test_rfc.py::test_rfc_80_frames_teacher_forced; profiles/r03_flow_completion_sensitivity.md).  So there
+  the test asserts the completed flows tightly OUTSIDE the flow mask (5e-3 px: they are the RAFT flows) and only
+  mean < 0.25 / max < 10 px inside; masks, schedules and the final frames keep their bounds.
 A live-oracle case covers configs[4]'s geometry (1280x720, nl 20: 60x107 -> 60x108 token grid, 405 pooled keys)."""
 import json
 from pathlib import Path
@@ -52,12 +63,16 @@ def synthetic_models(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fp16", ["enable", "disable"])
-@pytest.mark.parametrize("case", ["cfg1_node", "cfg2_24f_node", "cfg3_12f_node"])
+@pytest.mark.parametrize("case", ["cfg1_node", "cfg2_24f_node", "cfg3_12f_node", "cfg2_80f_node", "cfg4_100f_node", "mov_20f_node"])
 def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
+    if not (GOLD / f"{case}.npz").exists():
+        pytest.skip(f"{case}.npz not minted")
     g = np.load(GOLD / f"{case}.npz")
     P = json.loads(str(g["params_json"]))
     kind = str(g["kind"])
     image, mask = synth.synthetic_clip(P["T"], P["H"], P["W"])
+    if P.get("mask_kind", "static") == "moving":
+        mask = synth.moving_mask(P["T"], P["H"], P["W"])
     common = {k: P[k] for k in ("mask_dilates", "flow_mask_dilates", "ref_stride", "neighbor_length", "subvideo_length",
                                 "raft_iter")}
     nodes.TRACE = tr = {}
@@ -90,6 +105,11 @@ def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
     pf = tr["pred_flows"].cpu()[:, :, ::s, ::s].permute(0, 1, 4, 2, 3).numpy()
     d_pf = np.abs(pf - g["pred_flow"].astype(np.float32))
     e_pf, q_pf, m_pf = float(d_pf.max()), float(np.quantile(d_pf, 0.999)), float(d_pf.mean())
+    # outside the flow mask the completed flow IS the RAFT flow (combine_flow, recurrent_flow_completion.py:389-400):
+    # forward flows use the masks of frames 0..T-2, backward flows those of frames 1..T-1
+    fms = fm[:, ::s, ::s].astype(bool)
+    hole = np.stack([fms[:-1], fms[1:]], 0)[:, :, None]                                   # [2,T-1,1,h/s,w/s]
+    e_out = float((d_pf * ~hole).max())
     um = _unpack(g["updated_masks"], (T, h, w))
     frac_m = float((tr["updated_masks"].cpu().numpy() != um).mean())
     # ---- final frames ----------------------------------------------------------------------------------------------
@@ -102,10 +122,13 @@ def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
     p = psnr(got, want)
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     frac2 = float((diff > 2).mean())
-    print(f"{case} fp16={fp16}: gt_flow {e_gt:.2e} px, pred_flow max {e_pf:.2e} p99.9 {q_pf:.2e} mean {m_pf:.2e} px, upd_mask_frac {frac_m:.2e}, masked-pixel PSNR {p:.1f} dB, "
+    print(f"{case} fp16={fp16}: gt_flow {e_gt:.2e} px, pred_flow max {e_pf:.2e} (outside the hole {e_out:.2e}) p99.9 {q_pf:.2e} mean {m_pf:.2e} px, upd_mask_frac {frac_m:.2e}, masked-pixel PSNR {p:.1f} dB, "
           f"max {int(diff.max())} LSB, frac>2LSB {frac2:.2e}")
     assert e_gt < 2e-3
-    if fp16 == "disable":
+    assert e_out < 5e-3                              # RAFT flow + the fixture's f16 storage of flows of a few px
+    if T > 40:                                       # chaotic inside the hole (see the module docstring)
+        assert m_pf < 0.25 and e_pf < 10.0
+    elif fp16 == "disable":
         assert e_pf < 5e-2 and m_pf < 5e-3
     else:
         assert m_pf < 5e-2 and e_pf < 3.0

@@ -6,6 +6,7 @@ Prints us per launch, algorithmic TFLOP/s (4 * nq * nk * 128 per masked (window,
 (frame, window, head)) and the max error against a torch fp32 attention of two probe windows."""
 import argparse
 import math
+import os
 import sys
 from pathlib import Path
 
@@ -23,6 +24,8 @@ def main():
     ap.add_argument("--masked", type=int, default=-1, help="number of masked windows (default: centre block like cfg 2)")
     ap.add_argument("--reps", type=int, default=20)
     args = ap.parse_args()
+    if os.environ.get("PP_LIB"):   # an instrumented build of the library (tools/trace_attention.sh)
+        lib._lib = lib.Library(Path(os.environ["PP_LIB"]).resolve(), is_emulator=False)
     lib.load()
     dev = torch.device("cuda:0")
     t, fh, fw = args.t, args.fh, args.fw

@@ -45,6 +45,28 @@ __global__ void probe_mfma(const half_t* __restrict__ A, const half_t* __restric
   for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = c[r];
 }
 
+// (4) sustained matrix-pipe rate: every SIMD of the chip issues independent 32x32x16 f16 MFMAs back to back for ~1 ms;
+// reports TFLOP/s against the wall clock, and s_memtime ticks per MFMA (32 cycles each when the pipe is saturated -> the
+// tick rate of s_memtime and the clock the chip sustains under matrix load)
+__global__ void __launch_bounds__(256) probe_rate(float* out, long long* ticks, int iters) {
+  h8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (half_t)(0.001f * (threadIdx.x + j)); b[j] = (half_t)(0.002f * (threadIdx.x - j)); }
+  f16v c0, c1, c2, c3;
+  for (int i = 0; i < 16; ++i) c0[i] = c1[i] = c2[i] = c3[i] = 0.f;
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+  }
+  const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 int main() {
@@ -101,6 +123,23 @@ int main() {
     CK(hipMemcpy(D.data(), dD, 4096, hipMemcpyDeviceToHost));
     int b = 0; for (int i = 0; i < 1024; ++i) if (D[i] != R[i]) ++b;
     printf("mfma_f32_32x32x16_f16 fragment maps: %s (%d mismatches)\n", b ? "MISMATCH" : "ok", b); bad += b;
+  }
+  // (4)
+  {
+    const int nblk = 256 * 2, iters = 20000;   // 2 work-groups of 4 waves per CU: 2 waves per SIMD
+    float* dout; long long* dt; CK(hipMalloc(&dout, nblk * 256 * 4)); CK(hipMalloc(&dt, nblk * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    probe_rate<<<nblk, 256>>>(dout, dt, 100); CK(hipDeviceSynchronize());
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(e0)); probe_rate<<<nblk, 256>>>(dout, dt, iters); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      std::vector<long long> t(nblk); CK(hipMemcpy(t.data(), dt, nblk * 8, hipMemcpyDeviceToHost));
+      double avg = 0; for (auto v : t) avg += (double)v; avg /= nblk;
+      const double flop = (double)nblk * 4 * iters * 4 * 32768.0;
+      // per SIMD: 2 waves x 4 MFMAs x iters, 32 cycles each when saturated
+      printf("mfma rate: %.3f ms, %.0f TFLOP/s; s_memtime ticks per work-group %.0f = %.1f ticks per MFMA slot (32 cycles if saturated) -> tick rate %.0f MHz, implied core clock %.0f MHz\n",
+             ms, flop / ms / 1e9, avg, avg / (2.0 * 4 * iters), avg / ms / 1e3, (2.0 * 4 * iters * 32) / ms / 1e3);
+    }
   }
   printf(bad ? "PROBE FAILED\n" : "PROBE OK\n");
   return bad ? 1 : 0;
