@@ -105,7 +105,7 @@ def cpu_baseline(sds, models, dev, n_frames=12):
     per-window tensors of this workload stop scaling at a few tens of threads, so a 3-frame sweep picks the count."""
     host = os.cpu_count() or 1
     sweep = {}
-    for th in sorted({min(16, host), min(64, host), host}):
+    for th in sorted({min(8, host), min(16, host), min(32, host)}):   # (256 threads on the GPU box: minutes per frame)
         sweep[th] = round(_oracle_seconds(sds, 3, th)[0], 2)
     best = min(sweep, key=sweep.get)
     dt, ref, otr, inputs = _oracle_seconds(sds, n_frames, best)

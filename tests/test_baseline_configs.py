@@ -28,7 +28,8 @@ Tolerances (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact
   (1.4e-4 px from the reference's) lands 3.9 px max / 5e-2 mean from the reference's result, exactly where our fp32 and f16
   runs land (3.8 / 4.1 px), while the stage agrees to 1e-5 px with the oracle on identical input where the recurrence is
   stable (tests/test_rfc.py::test_rfc_80_frames_teacher_forced; profiles/r03_flow_completion_sensitivity.md).  So there
-  the test asserts the completed flows tightly OUTSIDE the flow mask (5e-3 px: they are the RAFT flows) and only
+  the test asserts the completed flows tightly OUTSIDE the flow mask (2e-3 px beyond the fixture's f16 storage
+  rounding: they are the RAFT flows) and only
   mean < 0.25 / max < 10 px inside; masks, schedules and the final frames keep their bounds.
 A live-oracle case covers configs[4]'s geometry (1280x720, nl 20: 60x107 -> 60x108 token grid, 405 pooled keys)."""
 import json
@@ -109,7 +110,8 @@ def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
     # forward flows use the masks of frames 0..T-2, backward flows those of frames 1..T-1
     fms = fm[:, ::s, ::s].astype(bool)
     hole = np.stack([fms[:-1], fms[1:]], 0)[:, :, None]                                   # [2,T-1,1,h/s,w/s]
-    e_out = float((d_pf * ~hole).max())
+    # (the fixture stores them as f16: half an ulp = 2^-11 relative, on flows of up to tens of px)
+    e_out = float(((d_pf - np.abs(g["pred_flow"].astype(np.float32)) * 2.0 ** -10) * ~hole).max())
     um = _unpack(g["updated_masks"], (T, h, w))
     frac_m = float((tr["updated_masks"].cpu().numpy() != um).mean())
     # ---- final frames ----------------------------------------------------------------------------------------------
@@ -125,7 +127,7 @@ def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
     print(f"{case} fp16={fp16}: gt_flow {e_gt:.2e} px, pred_flow max {e_pf:.2e} (outside the hole {e_out:.2e}) p99.9 {q_pf:.2e} mean {m_pf:.2e} px, upd_mask_frac {frac_m:.2e}, masked-pixel PSNR {p:.1f} dB, "
           f"max {int(diff.max())} LSB, frac>2LSB {frac2:.2e}")
     assert e_gt < 2e-3
-    assert e_out < 5e-3                              # RAFT flow + the fixture's f16 storage of flows of a few px
+    assert e_out < 2e-3                              # = the RAFT-flow bound, beyond the fixture's f16 storage rounding
     if T > 40:                                       # chaotic inside the hole (see the module docstring)
         assert m_pf < 0.25 and e_pf < 10.0
     elif fp16 == "disable":
