@@ -143,12 +143,21 @@ class GpuBackend:
     def to_frames(self, frames_u8):             # uint8 -> fp32 in [-1,1]  (image_utils.py:191)
         return ops.frames_from_u8(frames_u8.contiguous())
 
+    # geometry every rank can compute locally (r02 agreed on it with two 3-integer all_gathers on the critical path)
+    def enc_tail(self, hw):                     # encoder features of one frame: [H/4, W/4, 128]  (propainter.py:234-275)
+        return (hw[0] // 4, hw[1] // 4, 128)
+
+    def pred_tail(self, hw):                    # generator output of one local frame: [H, W, 4] (3 used)
+        return (hw[0], hw[1], 4)
+
 
 # ------------------------------------------------------------------------------------------------
 # the sharded driver (a generator: it yields communication requests and receives their results)
 #   yield tensor                      -> all_gather: the list of every rank's tensor (same shape everywhere)
 #   yield ("p2p", sends, recvs)       -> neighbour exchange: sends {peer: tensor}, recvs {peer: (shape, dtype)};
 #                                        the value sent back is {peer: tensor}
+#   yield ("p2p_start", sends, recvs) -> the same exchange posted asynchronously: the value sent back is a handle;
+#   yield ("p2p_wait", handle)        -> ... and completed: {peer: tensor}.  Work yielded in between runs under the transfer.
 # ------------------------------------------------------------------------------------------------
 def _pad_first(t: torch.Tensor, n: int) -> torch.Tensor:
     if t.shape[0] == n:
@@ -229,13 +238,28 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
         sub = backend.complete(gt, flow_masks_u8[s:e + 1])
         own.append(sub[:, f - s:e_own - s])
     own_flows = torch.cat(own, 1) if own else torch.zeros((2, 0) + hw + (2,), device=dev)
-    # x1: completed flows, 10 flows either side (image propagation halos; the windows' neighbour frames lie inside)
-    def flows_for_frames(r):          # completed flows read by rank r's image-propagation chunks (a rank may own frames
-        ch = plan.frame_chunks(r)     #  but no flow: the last frame of the clip)
-        a = plan.flow_ranges[r][0]
-        return (min(c[2] for c in ch), max(c[3] for c in ch) - 1) if ch else (a, a)
+    schedule = window_schedule(config)
+    ns = config.neighbor_length // 2
+    centers = [wi * ns for wi in range(len(schedule))]
 
-    need1 = [flows_for_frames(r) for r in range(plan.world)]
+    # x1: completed flows read by rank r: its image-propagation chunks (10 flows either side) AND the flows between the
+    # local (neighbour) frames of the windows centred in its frames -- feature propagation warps along them
+    # (propainter.py:149-205); for neighbor_length // 2 > 10 those reach beyond the image-propagation halo (r02 left them
+    # zero there: silently wrong seam windows for neighbor_length >= 22)
+    def flows_for_rank(r):
+        ch = plan.frame_chunks(r)     # (a rank may own frames but no flow: the last frame of the clip)
+        a = plan.flow_ranges[r][0]
+        if not ch:
+            return (a, a)
+        lo, hi = min(c[2] for c in ch), max(c[3] for c in ch) - 1
+        F0r, F1r = plan.frame_ranges[r]
+        for wi, c in enumerate(centers):
+            if F0r <= c < F1r:
+                nb = schedule[wi][0]
+                lo, hi = min(lo, nb[0]), max(hi, nb[-1])     # flows nb[0] .. nb[-1]-1
+        return (lo, hi)
+
+    need1 = [flows_for_rank(r) for r in range(plan.world)]
     pred_s = yield from _halo_exchange(own_flows.transpose(0, 1), plan.flow_ranges, plan.rank, need1)
     # ---- B: image propagation of the owned chunks, blend + encoder on the owned frames ---------------
     props, upds = [], []
@@ -244,10 +268,6 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
         p, m = backend.img_prop(frames_loc.rows(s, e), masks_dilated_u8[s:e], pr)
         props.append(p[f - s:e_own - s])
         upds.append(m[f - s:e_own - s])
-    schedule = window_schedule(config)
-    ns = config.neighbor_length // 2
-    centers = [wi * ns for wi in range(len(schedule))]
-
     def frames_of_windows(rng):       # frames read by the windows centred in `rng` (neighbours + references)
         ids = [i for wi, c in enumerate(centers) if rng[0] <= c < rng[1] for i in schedule[wi][0] + schedule[wi][1]]
         return (min(ids + [rng[0]]), max(ids + [rng[1] - 1]) + 1) if rng[1] > rng[0] else (rng[0], rng[0])
@@ -259,28 +279,16 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
     else:
         upd = masks_dilated_u8[0:0]
         enc_own = None
-    # the encoder's output geometry is only known to ranks that ran it: agree on it (3 integers)
-    enc_shape = yield torch.tensor(list(enc_own.shape[1:]) if enc_own is not None else [0, 0, 0], device=dev)
-    eshape = [int(v) for v in max(enc_shape, key=lambda t: int(t.sum()))]
-    if enc_own is None:
-        enc_own = torch.zeros([0] + eshape, device=dev, dtype=getattr(backend, "act_dtype", torch.float16))
+    if enc_own is None:   # an idle rank still takes part in the exchange: the geometry is a function of the frame size
+        enc_own = torch.zeros((0,) + tuple(backend.enc_tail(hw)), device=dev, dtype=getattr(backend, "act_dtype", torch.float16))
     # x2: encoder features + updated masks of the frames this rank's windows read (+-45 frames at the defaults)
     enc_s = yield from _halo_exchange(enc_own, plan.frame_ranges, plan.rank, need2)
     upd_s = yield from _halo_exchange(upd, plan.frame_ranges, plan.rank, need2)
     S0, S1 = need2[plan.rank]
     # ---- C: the windows centred in the owned frames, on a clip state over [S0, S1) only --------------------------
+    # x3 (window outputs that land on frames of another rank) is posted as soon as the SEAM windows are done and
+    # travels under the interior windows; it is waited for where compose needs it
     mine = [wi for wi, f in enumerate(centers) if F0 <= f < F1]
-    preds = {}
-    if mine:
-        flows_loc = torch.zeros((2, max(S1 - S0 - 1, 0)) + hw + (2,), device=dev)
-        x, y = max(S0, pred_s.lo), min(S1 - 1, pred_s.hi)        # flows beyond the halos are only between reference
-        if y > x:                                                #  frames and are never read
-            flows_loc[:, x - S0:y - S0] = pred_s.rows(x, y).transpose(0, 1)
-        st = backend.make_state(enc_s.t, flows_loc, masks_dilated_u8[S0:S1].contiguous(), upd_s.t)
-        loc = {wi: ([i - S0 for i in schedule[wi][0]], [i - S0 for i in schedule[wi][1]]) for wi in mine}
-        lp = backend.propagate_windows(st, [loc[wi][0] for wi in mine])
-        preds = {wi: backend.forward_window(st, loc[wi][0], loc[wi][1], lp[j]) for j, wi in enumerate(mine)}
-    # x3: window outputs that land on frames of another rank (the seam windows), peer to peer
     exports: list[dict[int, list[tuple[int, int]]]] = [dict() for _ in range(plan.world)]   # [src][dst] -> [(wi, idx)]
     for wi, (nb, _) in enumerate(schedule):
         src = plan.owner_of_frame(centers[wi])
@@ -288,15 +296,35 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
             dst = plan.owner_of_frame(idx)
             if dst != src:
                 exports[src].setdefault(dst, []).append((wi, idx))
+    seam_set = {wi for lst in exports[plan.rank].values() for wi, _ in lst}
+    seam = [wi for wi in mine if wi in seam_set]
+    interior = [wi for wi in mine if wi not in seam_set]
     H, W = hw
-    pred_tail = tuple(next(iter(preds.values())).shape[1:]) if preds else (H, W, 4)
-    tail_g = yield torch.tensor(list(pred_tail), device=dev)
-    pred_tail = tuple(int(v) for v in max(tail_g, key=lambda t: int(t.sum())))
-    sends = {dst: torch.stack([preds[wi][schedule[wi][0].index(idx)] for wi, idx in lst], 0)
-             for dst, lst in exports[plan.rank].items()}
+    pred_tail = tuple(backend.pred_tail(hw))
     recvs = {src: ((len(exports[src][plan.rank]),) + pred_tail, getattr(backend, "act_dtype", torch.float16))
              for src in range(plan.world) if src != plan.rank and plan.rank in exports[src]}
-    got = yield ("p2p", sends, recvs)
+    preds = {}
+    st = loc = None
+    if mine:
+        flows_loc = torch.zeros((2, max(S1 - S0 - 1, 0)) + hw + (2,), device=dev)
+        x, y = max(S0, pred_s.lo), min(S1 - 1, pred_s.hi)        # flows beyond [x, y) lie between reference frames only
+        if y > x:                                                #  and are never read (need1 covers the local frames)
+            flows_loc[:, x - S0:y - S0] = pred_s.rows(x, y).transpose(0, 1)
+        st = backend.make_state(enc_s.t, flows_loc, masks_dilated_u8[S0:S1].contiguous(), upd_s.t)
+        loc = {wi: ([i - S0 for i in schedule[wi][0]], [i - S0 for i in schedule[wi][1]]) for wi in mine}
+
+    def run_windows(group):
+        if group:
+            lp = backend.propagate_windows(st, [loc[wi][0] for wi in group])
+            for j, wi in enumerate(group):
+                preds[wi] = backend.forward_window(st, loc[wi][0], loc[wi][1], lp[j])
+
+    run_windows(seam)
+    sends = {dst: torch.stack([preds[wi][schedule[wi][0].index(idx)] for wi, idx in lst], 0)
+             for dst, lst in exports[plan.rank].items()}
+    handle = yield ("p2p_start", sends, recvs)
+    run_windows(interior)
+    got = yield ("p2p_wait", handle)
     foreign = {}
     for src, t in got.items():
         for j, key in enumerate(exports[src][plan.rank]):
@@ -349,19 +377,29 @@ def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8,
     def wire(t):
         return t.cpu() if via_host and t.is_cuda else t.contiguous()
 
+    def post(sends, recvs):
+        bufs = {peer: torch.empty(shape, dtype=dtype, device="cpu" if via_host else dev)
+                for peer, (shape, dtype) in recvs.items()}
+        keep = [wire(ten) for ten in sends.values()]         # the wire tensors must outlive the requests
+        p2p = [dist.P2POp(dist.irecv, buf, peer, group) for peer, buf in bufs.items()]
+        p2p += [dist.P2POp(dist.isend, ten, peer, group) for peer, ten in zip(sends.keys(), keep)]
+        return bufs, (dist.batch_isend_irecv(p2p) if p2p else []), keep
+
+    def finish(pending):
+        bufs, reqs, _keep = pending
+        for req in reqs:
+            req.wait()
+        return {peer: buf.to(dev) for peer, buf in bufs.items()}
+
     try:
         t = next(gen)
         while True:
-            if isinstance(t, tuple):
-                _, sends, recvs = t
-                bufs = {peer: torch.empty(shape, dtype=dtype, device="cpu" if via_host else dev)
-                        for peer, (shape, dtype) in recvs.items()}
-                p2p = [dist.P2POp(dist.irecv, buf, peer, group) for peer, buf in bufs.items()]
-                p2p += [dist.P2POp(dist.isend, wire(ten), peer, group) for peer, ten in sends.items()]
-                if p2p:
-                    for req in dist.batch_isend_irecv(p2p):
-                        req.wait()
-                out = {peer: buf.to(dev) for peer, buf in bufs.items()}
+            if isinstance(t, tuple) and t[0] == "p2p_start":
+                out = post(t[1], t[2])
+            elif isinstance(t, tuple) and t[0] == "p2p_wait":
+                out = finish(t[1])
+            elif isinstance(t, tuple):
+                out = finish(post(t[1], t[2]))
             else:
                 th = wire(t)
                 outh = [torch.empty_like(th) for _ in range(plan.world)]
@@ -381,7 +419,18 @@ def run_simulated(make_backend, world: int, config: ProPainterConfig, frames_u8,
     while any(r is None for r in results):
         nxt = []
         for r, g in enumerate(gens):
-            if isinstance(vals[r], tuple):      # neighbour exchange: what every peer addressed to rank r
+            if isinstance(vals[r], tuple) and vals[r][0] == "p2p_start":
+                # every rank posts in the same lock-step round: deliver at once, hand the result back at the wait
+                _, _, recvs = vals[r]
+                reply = {}
+                for src, (shape, dtype) in recvs.items():
+                    t = vals[src][1][r]
+                    assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (src, r, tuple(t.shape), shape)
+                    reply[src] = t.clone()
+                assert all(r in vals[dst][2] for dst in vals[r][1]), "a send without a matching receive"
+            elif isinstance(vals[r], tuple) and vals[r][0] == "p2p_wait":
+                reply = vals[r][1]
+            elif isinstance(vals[r], tuple):    # neighbour exchange: what every peer addressed to rank r
                 _, _, recvs = vals[r]
                 reply = {}
                 for src, (shape, dtype) in recvs.items():

@@ -3,9 +3,8 @@
 CPU: the real driver (comfyui_propainter_nodes_amd/distributed.py) over torch.distributed/gloo with world_size 2 and 3,
 stage functions replaced by a toy backend; the sharded result must equal the single-rank result exactly.
 GPU: the same driver with the real MI355X backend (in-process virtual ranks, and two real processes over gloo) must
-reproduce the single-GPU pipeline on the chunked fixture: bit for bit when the convolution kernel selection is pinned
-(PP_CONV_KSPLIT=0: the in-work-group split-K kernel is chosen by problem size, a rank's smaller batches can select it where
-the single-GPU run does not, and its partial sums add in another order), within 1 LSB of the uint8 frames otherwise."""
+reproduce the single-GPU pipeline on the chunked fixture bit for bit (r03: every kernel choice is a function of the layer
+shape, never of how many frames / windows a rank batches); two ranks over RCCL ("nccl") when the box has two GPUs."""
 import os
 from pathlib import Path
 
@@ -65,7 +64,7 @@ def _worker(rank, world, port, T, nl, rs, sv, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,T,nl,rs,sv", [(2, 40, 6, 3, 10), (3, 37, 4, 2, 10), (2, 9, 4, 2, 4)])
+@pytest.mark.parametrize("world,T,nl,rs,sv", [(2, 40, 6, 3, 10), (3, 37, 4, 2, 10), (2, 9, 4, 2, 4), (2, 60, 30, 10, 15)])
 def test_sharded_equals_single_rank_over_gloo(tmp_path, world, T, nl, rs, sv):
     import sys
 
@@ -83,6 +82,14 @@ def test_sharded_equals_single_rank_over_gloo(tmp_path, world, T, nl, rs, sv):
     sim = D.run_simulated(lambda r: ToyBackend(), world, _cfg(T, nl, rs, sv), frames, fm, md)
     assert all(torch.equal(s, ref) for s in sim)
     assert ref.float().std() > 10  # the toy clip is not degenerate
+    # ... and not saturated: zeroing the completed flows of the seam region must change the single-rank result
+    class ZeroFlows(ToyBackend):
+        def make_state(self, enc, flows, md, upd):
+            flows = flows.clone()
+            flows[:, flows.shape[1] // 2:] = 0
+            return super().make_state(enc, flows, md, upd)
+    broken = D.run_simulated(lambda r: ZeroFlows(), 1, _cfg(T, nl, rs, sv), frames, fm, md)[0]
+    assert not torch.equal(broken, ref), "the toy backend hides wrong flows"
 
 
 @pytest.mark.parametrize("world,T,nl,rs,sv", [
@@ -91,6 +98,8 @@ def test_sharded_equals_single_rank_over_gloo(tmp_path, world, T, nl, rs, sv):
     (8, 17, 6, 3, 100),  # more ranks than chunks: 7 idle ranks take part in every exchange
     (3, 2, 2, 1, 1),     # a single flow
     (2, 23, 10, 5, 7),   # ragged last chunk
+    (2, 60, 30, 10, 15), # neighbor_length // 2 = 15 > 10: seam windows read flows beyond the image-propagation halo
+    (3, 50, 24, 6, 10),  # the same with rank boundaries that are not window centres
 ])
 def test_sharded_equals_single_rank_edge_cases(world, T, nl, rs, sv):
     """In-process virtual ranks (the same generator the RCCL runner drives) on shard plans with short chunks, idle
@@ -116,12 +125,10 @@ def _assert_same_frames(got, single, exact, what):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pinned", [True, False])
-def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib, monkeypatch, pinned):
+def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib, monkeypatch):
     from comfyui_propainter_nodes_amd import weights
 
-    if pinned:
-        monkeypatch.setenv("PP_CONV_KSPLIT", "0")
+    pinned = True  # r03: kernel selection depends on the layer, never on a rank's batch -> bit-identical by default
     # (virtual ranks share one model object: its captured recurrence graphs hand out static buffers, which two ranks
     #  advancing in lock-step would overwrite for each other -- a real rank has its own process and models)
     monkeypatch.setenv("PP_GRAPHS", "0")
@@ -139,20 +146,25 @@ def test_sharded_gpu_pipeline_is_bit_identical_to_single_gpu(hip_lib, monkeypatc
             _assert_same_frames(res[r].cpu(), single, pinned, f"world {world} rank {r}")
 
 
-def _gpu_worker(rank, world, port, out_dir):
+def _gpu_worker(rank, world, port, out_dir, backend="gloo"):
     """One REAL process per rank, the real MI355X backend, a real process group (gloo: both ranks share the one GPU
-    of the test box, tensors are staged through the host for the collectives)."""
+    of the test box, tensors are staged through the host for the collectives; nccl = RCCL: one GPU per rank)."""
     import torch.distributed as dist
 
     from comfyui_propainter_nodes_amd import lib, weights
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     lib.load()
     g = np.load(GOLD / "e2e_chunked.npz")
     T, H, W, iters, nl, rs, sv, _, _, seed = [int(v) for v in g["params"]]
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
     models = pipeline.models_from_state_dicts(weights.synth_state_dicts(seed), dev)
     cfg = pipeline.ProPainterConfig(rs, nl, sv, iters, "enable", T, dev, (W, H))
     fr, fm, md = (torch.from_numpy(g[k]).to(dev) for k in ("frames_u8", "flow_masks", "masks_dilated"))
@@ -165,15 +177,27 @@ def _gpu_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pinned", [True, False])
-def test_two_processes_with_the_gpu_backend_match_single_process(hip_lib, tmp_path, monkeypatch, pinned):
-    if pinned:
-        monkeypatch.setenv("PP_CONV_KSPLIT", "0")  # inherited by the spawned ranks
-    port = 29500 + (os.getpid() * 3 + 11 + int(pinned)) % 2000
+def test_two_processes_with_the_gpu_backend_match_single_process(hip_lib, tmp_path):
+    pinned = True  # bit-identical by default (see above)
+    port = 29500 + (os.getpid() * 3 + 11) % 2000
     mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     single = torch.load(tmp_path / "single.pt")
     for r in range(2):
         _assert_same_frames(torch.load(tmp_path / f"r{r}.pt"), single, pinned, f"rank {r}")
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_match_single_process(hip_lib, tmp_path):
+    """The RCCL branch of the runner (backend "nccl", device tensors on the wire, grouped isend / irecv + all_gather over
+    xGMI): two ranks, one GPU each, against the single-process result.  Skips on a 1-GPU box (gpurun); runs on the driver's
+    multi-GPU node so that the branch the SCALE bench uses has been executed before it is timed."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL, one rank per GPU)")
+    port = 29500 + (os.getpid() * 5 + 17) % 2000
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    single = torch.load(tmp_path / "single.pt")
+    for r in range(2):
+        _assert_same_frames(torch.load(tmp_path / f"r{r}.pt"), single, True, f"rank {r} (RCCL)")
 
 
 @pytest.mark.gpu

@@ -8,6 +8,12 @@ class ToyBackend:
     def to_frames(self, frames_u8):
         return frames_u8.float() / 255.0 * 2 - 1
 
+    def enc_tail(self, hw):
+        return (1, 1, 4)
+
+    def pred_tail(self, hw):
+        return (hw[0], hw[1], 4)
+
     def raft(self, frames):
         a, b = frames[:-1, ..., :2], frames[1:, ..., :2]
         return torch.stack([b - a + 0.1 * a * b, a - b + 0.05 * a], 0)
@@ -39,9 +45,12 @@ class ToyBackend:
         for nb in windows:
             e = st["enc"][nb[0]:nb[-1] + 1]
             fl = st["flows"][:, nb[0]:nb[-1]].mean((2, 3, 4)) if len(nb) > 1 else torch.zeros(2, 0)
-            acc = torch.cumsum(e, 0) + torch.flip(torch.cumsum(torch.flip(e, [0]), 0), [0])
-            acc[1:] += fl[0].view(-1, 1, 1, 1)
-            acc[:-1] += fl[1].view(-1, 1, 1, 1)
+            # means, not sums: the output must stay sensitive to every flow / feature whatever the window length
+            n = e.shape[0]
+            w = torch.arange(1, n + 1, dtype=torch.float32).view(-1, 1, 1, 1)
+            acc = torch.cumsum(e, 0) / w + torch.flip(torch.cumsum(torch.flip(e, [0]), 0) / w, [0])
+            acc[1:] += 3.0 * fl[0].view(-1, 1, 1, 1)
+            acc[:-1] += 3.0 * fl[1].view(-1, 1, 1, 1)
             out.append(acc)
         return out
 
@@ -49,7 +58,8 @@ class ToyBackend:
         H, W = st["md"].shape[1:]
         ref = st["enc"][refs].sum() if refs else torch.tensor(0.0)
         # (nothing here may depend on absolute frame numbers: a rank works on a clip state over its own frames + halos)
-        val = torch.tanh(local_prop.sum((1, 2, 3)) * 0.3 + 0.01 * ref + 0.001 * torch.arange(len(nb), dtype=torch.float32))
+        # un-saturated on purpose (|val| stays well below 1): zero or wrong flows / features change the uint8 result
+        val = torch.tanh(local_prop.mean((1, 2, 3)) * 0.25 + 0.002 * ref / max(len(refs), 1) + 0.001 * torch.arange(len(nb), dtype=torch.float32))
         ramp = torch.linspace(-0.2, 0.2, H * W).view(1, H, W, 1)
         return (val.view(-1, 1, 1, 1) * 0.7 + ramp).expand(-1, H, W, 4).contiguous().half()
 
