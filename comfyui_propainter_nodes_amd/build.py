@@ -88,7 +88,7 @@ def _compile_all(objs_dir: Path, compile_one, link, out: Path, stamp_extra: str,
 
 # translation units with hidden (inline-asm) loads: their gfx950 ISA is kept next to the object so that
 # tests/test_isa_audit.py audits the code that ships instead of compiling a second copy
-ISA_KEPT = ("conv_split", "conv_halo", "conv_halo_tall")
+ISA_KEPT = ("conv_split", "conv_halo")
 
 
 def isa_path(stem: str) -> Path:

@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <type_traits>
+
+#include "pp_options.h"
 #include <utility>
 
 namespace pp {
@@ -357,14 +359,7 @@ static int launch_by_cout(void* stream, const ConvK& k, int Z) {
   // 633 ms), 32-pixel tiles for the per-step convolutions of the recurrences and 16-pixel tiles when even those leave
   // CUs idle (-> 627 ms).  PP_CONV_TILE pins one family for tests: large | small | xlforce | tiny | classic
   // (classic = the r01 rules: no 8-wave and no 16-pixel tiles).
-  static const int forced = [] {
-    const char* e = getenv("PP_CONV_TILE");
-    if (!e) return 0;
-    if (e[0] == 'x') return strcmp(e, "xlforce") == 0 ? 4 : 0;
-    if (e[0] == 't') return 5;
-    if (e[0] == 'c') return 6;
-    return e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
-  }();
+  const int forced = options().tile;
   const bool small = forced == 2 || ((forced == 0 || forced == 5 || forced == 6) && blocks128 < 224);
   // (... for every Cout whose padding to 256-channel tiles wastes no more than 128-channel tiles would, and at most 1/8)
   const int waste256 = (k.Cout + 255) / 256 * 256 - k.Cout;
@@ -406,8 +401,6 @@ int launch_split(void* stream, const ConvK& k, int Z);
 int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // ... and its halo-tile form for stride-1 multi-tap convolutions (conv_halo.hip); returns 1 when not eligible
 int launch_halo_split(void* stream, const ConvK& k, int Z);
-// conv_halo_tall.hip: 16-row tiles, one wave per SIMD (3x3 / 1x5 / 5x1, Cout > 64); returns 1 when not eligible
-int launch_halo_tall(void* stream, const ConvK& k, int Z);
 int launch_halo_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // conv_direct.hip: at most 4 output channels, streaming fp32-FMA kernel; returns 1 when not eligible
 int launch_direct_small_cout(void* stream, const ConvK& k, int Z, int dtype, bool out_f16);

@@ -190,16 +190,17 @@ static int launch_direct_t(void* stream, const ConvK& k, int wmode) {
 
 // returns 1 when the convolution is not eligible (the caller goes on to the implicit-GEMM kernels): at most 4 output
 // channels, one input segment, stride 1, dilation 1, zero padding, at most 3 x 3 taps, one z slice, and enough
-// pixels that the layer is a streaming problem (>= 16384; below that the MFMA tiles' latency is the better trade).
-// PP_CONV_DIRECT=0 disables, "force" lifts the size rule (tests).
+// pixels PER IMAGE that the layer is a streaming problem (>= 2048: RAFT's flow head at 45 x 80 and everything larger; the
+// rule looks at one image, never at the batch, so that a rank of a sharded run picks the same kernel as the single-GPU run).
+// PP_CONV_DIRECT=0 disables, "force" lifts the size rule (tests) -- pp_options.h.
 int launch_direct_small_cout(void* stream, const ConvK& k, int Z, int dtype, bool out_f16) {
-  const char* e = getenv("PP_CONV_DIRECT");
-  if (e && e[0] == '0') return 1;
-  const bool force = e && e[0] == 'f';
+  const int mode = options().direct;
+  if (mode == 0) return 1;
+  const bool force = mode == 2;
   if (k.Cout > 4 || k.nseg != 1 || Z != 1 || k.sh != 1 || k.sw != 1 || k.dh != 1 || k.dw != 1 || k.pad_mode != PP_PAD_ZEROS) return 1;
   if (k.kh > 3 || k.kw > 3) return 1;
   if (k.Ho != k.H + 2 * k.ph - (k.kh - 1) || k.Wo != k.W + 2 * k.pw - (k.kw - 1)) return 1;
-  if (!force && k.M < 16384) return 1;
+  if (!force && (int64_t)k.Ho * k.Wo < 2048) return 1;
   if (dtype == PP_F16) return out_f16 ? launch_direct_t<half_t, half_t>(stream, k, dtype) : launch_direct_t<half_t, float>(stream, k, dtype);
   if (out_f16) return 1;
   return launch_direct_t<float, float>(stream, k, dtype);

@@ -632,11 +632,10 @@ int launch_halo_split(void* stream, const ConvK& k, int Z) {
 // PP_CONV_HALO_CT=0 keeps the runtime-tap kernel everywhere (A/B runs, tests)
 template <int WC, int WP, int TC, int TP>
 static int launch_halo_any(void* stream, const ConvK& k, int Z, const HaloGeom& g) {
-  const char* e = getenv("PP_CONV_HALO_CT");
   int64_t max_ldc = 0;
   for (int sgm = 0; sgm < k.nseg; ++sgm) max_ldc = k.in_ldc[sgm] > max_ldc ? k.in_ldc[sgm] : max_ldc;
   const bool off32 = (int64_t)k.N * k.H * k.W * max_ldc < ((int64_t)1 << 30) && (int64_t)k.Cout * k.Kp < ((int64_t)1 << 30);
-  if (!(e && e[0] == '0') && k.dh == 1 && k.dw == 1 && off32) {
+  if (options().halo_ct && k.dh == 1 && k.dw == 1 && off32) {
     if (k.kh == 3 && k.kw == 3) return launch_halo_ct_cfg<WC, WP, TC, TP, 3, 3>(stream, k, Z, g);
     if (k.kh == 1 && k.kw == 5) return launch_halo_ct_cfg<WC, WP, TC, TP, 1, 5>(stream, k, Z, g);
     if (k.kh == 5 && k.kw == 1) return launch_halo_ct_cfg<WC, WP, TC, TP, 5, 1>(stream, k, Z, g);

@@ -1,6 +1,7 @@
 // conv_halo_common.h -- geometry / eligibility shared by the two halo-tile translation units (conv_halo.hip: PP_F32X2,
 // conv_halo_f16.hip: f16).
 #pragma once
+#include "pp_options.h"
 #include "conv_common.h"
 
 #include <stdio.h>
@@ -19,12 +20,8 @@ constexpr int kHaloTW = 16;
 constexpr int kHaloMaxRows = 192;
 
 // PP_CONV_HALO=0 keeps every PP_F32X2 convolution on conv_split_kernel; "force" uses the halo kernel for every
-// eligible geometry regardless of the problem size (tests).
-static inline int halo_mode() {  // (read per call: a getenv is noise next to a kernel launch, and tests switch it in-process)
-  const char* e = getenv("PP_CONV_HALO");
-  if (!e) return 1;
-  return e[0] == '0' ? 0 : (e[0] == 'f' ? 2 : 1);
-}
+// eligible geometry regardless of the problem size (tests) -- pp_options.h.
+static inline int halo_mode() { return options().halo; }
 
 // Geometry + eligibility shared by both forms; returns false when the flat-tile kernels should run instead.
 static inline bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* g, int TH = 8) {
@@ -50,8 +47,7 @@ static inline bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* 
   }
   g->ntiles = (int)ntiles;
   g->nct = 0;
-  static const bool trace = getenv("PP_CONV_TRACE") != nullptr;  // debugging aid: which kernel family ran
-  if (trace) fprintf(stderr, "pp_conv2d: halo-tile kernel (%d-row tiles), %dx%d taps, Cout %d, %d tiles\n", TH, k.kh, k.kw, k.Cout, g->ntiles);
+  if (options().trace) fprintf(stderr, "pp_conv2d: halo-tile kernel (%d-row tiles), %dx%d taps, Cout %d, %d tiles\n", TH, k.kh, k.kw, k.Cout, g->ntiles);
   return true;
 }
 

@@ -237,10 +237,9 @@ static int launch_ksplit_t(void* stream, const ConvK& k, int Z) {
 // function of the LAYER (pixels of one image, Cout, K) and never of the batch: split-K sums the chunks in a different
 // order than the flat tiles, and a rank of a sharded run that batches fewer windows / frames than the single-GPU run must
 // still pick the same kernel for the same layer so that both runs agree bit for bit (r02 decided on N*Ho*Wo).
-// PP_CONV_KSPLIT=0 disables, "force" selects it for every f16 problem with at least 4 chunks (tests).
+// PP_CONV_KSPLIT=0 disables, "force" selects it for every f16 problem with at least 4 chunks (tests) -- pp_options.h.
 int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16) {
-  const char* e = getenv("PP_CONV_KSPLIT");
-  const int mode = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'f' ? 2 : 1));
+  const int mode = options().ksplit;
   if (mode == 0 || k.nchunks < kKS) return 1;
   if (mode != 2) {
     const int64_t img_blocks32 = (((int64_t)k.Ho * k.Wo + 31) / 32) * ((k.Cout + 127) / 128);

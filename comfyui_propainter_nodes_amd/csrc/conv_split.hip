@@ -318,9 +318,7 @@ struct SplitFamily {
 };
 
 int launch_split(void* stream, const ConvK& k, int Z) {
-  int rc = launch_halo_tall(stream, k, Z);         // large 3x3 / 1x5 / 5x1 problems: 16-row tiles, one wave per SIMD
-  if (rc != 1) return rc;
-  rc = launch_halo_split(stream, k, Z);            // stride-1 multi-tap convolutions: pixel tile + halo staged once per chunk
+  const int rc = launch_halo_split(stream, k, Z);  // stride-1 multi-tap convolutions: pixel tile + halo staged once per chunk
   if (rc != 1) return rc;
   return launch_by_cout<SplitFamily<float>>(stream, k, Z);
 }

@@ -1,8 +1,10 @@
 // pp_api.hip -- library-level entry points of libpropainter_mi355 (version, errors, ABI self-check).
 #include "pp_device.h"
 #include "pp_host.h"
+#include "pp_options.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace pp {
 
@@ -35,7 +37,40 @@ void pp_allow_big_lds(const void* func, size_t bytes) {
 #endif
 }
 
+static Options g_options;
+static bool g_options_loaded = false;
+
+static int tri(const char* name) {  // unset -> 1 (auto), "0..." -> 0, "f..." -> 2
+  const char* e = getenv(name);
+  return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'f' ? 2 : 1));
+}
+
+static void load_options() {
+  Options o;
+  o.halo = tri("PP_CONV_HALO");
+  o.halo_ct = tri("PP_CONV_HALO_CT") == 0 ? 0 : 1;
+  o.ksplit = tri("PP_CONV_KSPLIT");
+  o.direct = tri("PP_CONV_DIRECT");
+  o.trace = getenv("PP_CONV_TRACE") != nullptr;
+  o.tile = 0;
+  if (const char* e = getenv("PP_CONV_TILE")) {
+    if (e[0] == 'x') o.tile = strcmp(e, "xlforce") == 0 ? 4 : 0;
+    else if (e[0] == 't') o.tile = 5;
+    else if (e[0] == 'c') o.tile = 6;
+    else o.tile = e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
+  }
+  g_options = o;
+  g_options_loaded = true;
+}
+
+const Options& options() {
+  if (!g_options_loaded) load_options();
+  return g_options;
+}
+
 }  // namespace pp
+
+extern "C" void pp_reload_options(void) { pp::load_options(); }
 
 extern "C" int32_t pp_version(void) { return PP_ABI_VERSION; }
 

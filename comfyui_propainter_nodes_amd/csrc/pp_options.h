@@ -1,0 +1,22 @@
+// pp_options.h -- the library's tuning / test knobs, read from the environment ONCE (first use) and again only when
+// pp_reload_options() is called (tests that switch a knob inside one process).  Every knob pins a kernel family for
+// tests or A/B runs; none changes results beyond the summation order of the selected kernel.
+//   PP_CONV_HALO     0 | force   halo-tile kernels off / for every eligible geometry regardless of the problem size
+//   PP_CONV_HALO_CT  0           runtime-tap halo kernels instead of the compile-time-tap ones
+//   PP_CONV_KSPLIT   0 | force   in-work-group split-K kernel off / for every f16 problem with >= 4 chunks
+//   PP_CONV_TILE     large | small | xlforce | tiny | classic   pin one flat-tile family
+//   PP_CONV_DIRECT   0 | force   <= 4-output-channel streaming kernel off / regardless of the image size
+//   PP_CONV_TRACE    (set)       print which convolution kernel family ran (debugging aid)
+#pragma once
+
+namespace pp {
+struct Options {
+  int halo;     // 0 off, 1 auto, 2 force
+  int halo_ct;  // 0 runtime taps, 1 auto
+  int ksplit;   // 0 off, 1 auto, 2 force
+  int tile;     // 0 auto, 1 large, 2 small, 4 xlforce, 5 tiny, 6 classic
+  int direct;   // 0 off, 1 auto, 2 force
+  int trace;
+};
+const Options& options();
+}  // namespace pp

@@ -38,6 +38,11 @@ class ClipState:
         self.maskpair = None   # f16 [T,h,w,8] (m_in, m_updated, 0...)
         self.tokmask = None    # u8 [T,fh,fw]: MaxPool2d(7,3,3) of the 1/4-res dilated mask
         self.H = self.W = 0
+        # static masks (one MASK frame replicated over the clip, or the two border planes of an outpaint canvas): the token
+        # mask is the same in every frame, so the masked-window set is ONE constant of the clip -- or, with a hashable key
+        # (outpaint geometry), of every clip with that geometry
+        self.static_masks = False
+        self.flags = None
 
 
 class InpaintGeneratorMI355:
@@ -48,6 +53,7 @@ class InpaintGeneratorMI355:
         probabilities to f16 for its MFMAs and keeps scores, statistics, accumulators and outputs in fp32."""
         self.device = torch.device(device)
         self.dt = dtype
+        self._geometry_flags: dict = {}   # outpaint geometry -> masked-window flags (window_mask_flags)
         self.split = dtype == torch.float32 and ops.f32_split_enabled()
         self._graphs = graphs.GraphCache()
         p = {k: v.float() for k, v in sd.items() if v.is_floating_point()}
@@ -153,10 +159,11 @@ class InpaintGeneratorMI355:
         return out
 
     def prepare_clip(self, packed: torch.Tensor | None, flows: torch.Tensor, masks_in_u8: torch.Tensor,
-                     masks_upd_u8: torch.Tensor, enc: torch.Tensor | None = None) -> ClipState:
+                     masks_upd_u8: torch.Tensor, enc: torch.Tensor | None = None, static_masks=False) -> ClipState:
         """packed f16 [T,H,W,8] (or precomputed encoder features `enc` f16 [T,h,w,128], e.g. gathered from
         other ranks); flows fp32 [2,T-1,H,W,2] (completed); masks u8 [T,H,W] on the device."""
         st = ClipState()
+        st.static_masks = static_masks
         T, H, W = masks_in_u8.shape
         dev = masks_in_u8.device
         st.H, st.W = H, W
@@ -285,7 +292,18 @@ class InpaintGeneratorMI355:
     def window_mask_flags(self, st: ClipState, nb: list[int]) -> torch.Tensor:
         """Integer logic of sparse_transformer.py:321-326: a 5x9 token window is 'masked' iff any
         local-frame token mask inside it is set (computed on the device, no host sync)."""
-        return ops.window_flags(st.tokmask, nb[0], len(nb), WIN)
+        if not st.static_masks:
+            return ops.window_flags(st.tokmask, nb[0], len(nb), WIN)
+        if st.flags is None:
+            key = (st.static_masks, st.H, st.W, str(st.tokmask.device)) if st.static_masks is not True else None
+            st.flags = self._geometry_flags.get(key) if key is not None else None
+            if st.flags is None:
+                st.flags = ops.window_flags(st.tokmask, 0, 1, WIN)   # any frame: they are all the same
+                if key is not None:
+                    if len(self._geometry_flags) > 64:
+                        self._geometry_flags.clear()
+                    self._geometry_flags[key] = st.flags
+        return st.flags
 
     def forward_window(self, st: ClipState, nb: list[int], refs: list[int], trace: dict | None = None,
                        local_prop: torch.Tensor | None = None) -> torch.Tensor:

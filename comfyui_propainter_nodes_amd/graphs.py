@@ -46,18 +46,25 @@ class GraphCache:
         self._entries: "OrderedDict[tuple, _Entry]" = OrderedDict()
 
     def clear(self) -> None:
+        """Drop the captured sweeps and their private memory pools (several GB per clip shape; torch's empty_cache does
+        not release them while the graphs are alive).  The caches die with the models: pipeline.drop_model_cache()."""
         self._entries.clear()
 
     def run(self, key: tuple, fn: Callable, *inputs: torch.Tensor):
         if not enabled(*inputs):
             return fn(*inputs)
         key = key + tuple((tuple(t.shape), t.dtype, str(t.device)) for t in inputs)
+        # capture, warm-up and replay on the device of the inputs (not whatever device happens to be current)
+        with torch.cuda.device(inputs[0].device):
+            return self._run_on_device(key, fn, inputs)
+
+    def _run_on_device(self, key: tuple, fn: Callable, inputs):
         e = self._entries.get(key)
         if e is None:
             static_in = [torch.empty_like(t, memory_format=torch.contiguous_format).copy_(t) for t in inputs]
             # warm-up on a side stream (torch's capture recipe): one-time initialisation (LDS attributes, cached index
             # tensors, allocator growth) must not happen inside the capture
-            s = torch.cuda.Stream()
+            s = torch.cuda.Stream(inputs[0].device)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 fn(*static_in)

@@ -102,6 +102,7 @@ class Library:
         self.cdll.pp_struct_size.restype = ctypes.c_int64
         self.cdll.pp_struct_size.argtypes = [ctypes.c_char_p]
         self.cdll.pp_version.restype = ctypes.c_int32
+        self.cdll.pp_reload_options.restype = None
         if self.cdll.pp_version() != CONSTS["PP_ABI_VERSION"]:
             raise ABIError("libpropainter ABI version mismatch with the header")
         for name, st in STRUCTS.items():
@@ -127,6 +128,12 @@ def load() -> Library:
     if _lib is None:
         _lib = Library(HIP_LIB, is_emulator=False)
     return _lib
+
+
+def reload_options() -> None:
+    """Re-read the PP_CONV_* knobs from the environment (the library caches them at first use)."""
+    if _lib is not None:
+        _lib.cdll.pp_reload_options()
 
 
 def unload() -> None:

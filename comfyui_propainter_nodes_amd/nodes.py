@@ -90,7 +90,7 @@ def _device_io_ok(image: torch.Tensor, process_size, input_size, mask: torch.Ten
     resize, exotic dtypes) takes the host path of image_utils.py, which is the reference's own."""
     if os.environ.get("PP_HOST_IO") == "1":
         return False
-    if tuple(process_size) != tuple(input_size) or image.dtype != torch.float32:
+    if tuple(process_size) != tuple(input_size) or image.dtype != torch.float32 or image.dim() != 4 or image.shape[-1] != 3:
         return False
     return mask is None or mask.dtype == torch.float32
 
@@ -124,10 +124,13 @@ class _HostImageSink:
 
         self.device = device
         key = (T, H, W)
-        if key not in _HostImageSink._pinned:      # page-locking 55 MB costs more than the copy: keep the buffer
+        # page-locking 55 MB costs more than the copy: one buffer is kept between calls and OWNED by one sink at a time
+        # (a second node execution overlapping this one, or a worker that outlived an abandoned call, gets its own)
+        with _HostImageSink._lock:
+            buf = _HostImageSink._pinned.pop(key, None)
             _HostImageSink._pinned.clear()
-            _HostImageSink._pinned[key] = torch.empty(T, H, W, 3, dtype=torch.uint8).pin_memory()
-        self.pinned = _HostImageSink._pinned[key]
+        self.key = key
+        self.pinned = buf if buf is not None else torch.empty(T, H, W, 3, dtype=torch.uint8).pin_memory()
         self.image = torch.empty(T, H, W, 3, dtype=torch.float32)
         self.stream = torch.cuda.Stream(device)
         self.q: "queue.Queue" = queue.Queue()
@@ -136,6 +139,12 @@ class _HostImageSink:
         self.worker.start()
 
     _pinned: dict = {}
+    _lock = __import__("threading").Lock()
+
+    def _release(self) -> None:
+        with _HostImageSink._lock:
+            _HostImageSink._pinned.clear()
+            _HostImageSink._pinned[self.key] = self.pinned
 
     def frames_final(self, comp: torch.Tensor, lo: int, hi: int) -> None:
         ready = torch.cuda.Event()
@@ -178,11 +187,15 @@ class _HostImageSink:
 
     def abandon(self) -> None:
         self.q.put(None)
+        self.stream.synchronize()          # no copy into the pinned buffer may still be in flight
         self.worker.join(timeout=5.0)
+        if not self.worker.is_alive():     # (a worker that is still converting keeps the buffer: it is not handed on)
+            self._release()
 
     def finish(self) -> torch.Tensor:
         self.q.put(None)
         self.worker.join()
+        self._release()
         if self.error is not None:
             raise self.error
         return self.image
@@ -191,13 +204,14 @@ class _HostImageSink:
 TRACE: dict | None = None  # debugging / test aid: when a dict, the next node call leaves its stage tensors in it
 
 
-def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer):
+def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer, static_masks=False):
     if TRACE is not None:
         TRACE.update(frames_u8=fr_u8, flow_masks=fm, masks_dilated=md)
     stream_out = fr_u8.is_cuda and os.environ.get("PP_OUTPUT", "stream") == "stream" and TRACE is None
     sink = _HostImageSink(*fr_u8.shape[:3], fr_u8.device) if stream_out else None
     try:
-        comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32, sink=sink)
+        comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32, sink=sink,
+                              static_masks=static_masks)
     except BaseException:
         if sink is not None:
             sink.abandon()             # release the worker thread: a failed call must not leave it parked on the queue
@@ -259,7 +273,7 @@ class ProPainterInpaint:
             fm, md = torch.from_numpy(flow_masks).to(device), torch.from_numpy(masks_dilated).to(device)
         tm.mark("input(H2D, u8, masks)")
         print(f"\nProcessing  {config.video_length} frames...")
-        return _run(models, config, fr_u8, fr_f32, fm, md, tm)
+        return _run(models, config, fr_u8, fr_f32, fm, md, tm, static_masks=mask.shape[0] == 1)
 
 
 class ProPainterOutpaint:
@@ -310,7 +324,10 @@ class ProPainterOutpaint:
             fm, md = torch.from_numpy(flow_masks).to(device), torch.from_numpy(masks_dilated).to(device)
         tm.mark("input(H2D, u8, masks)")
         print(f"\nProcessing  {config.video_length} frames...")
-        output_frames, output_masks, _ = _run(models, config, fr_u8, fr_f32, fm, md, tm)
+        # the border masks are a function of the canvas geometry alone: the masked-window set of the transformer is cached
+        # per geometry across node executions (image_utils.py:200-252 recomputes the planes per call)
+        geometry = ("outpaint", tuple(config.process_size), tuple(input_size), mask_dilates, float(width_scale), float(height_scale))
+        output_frames, output_masks, _ = _run(models, config, fr_u8, fr_f32, fm, md, tm, static_masks=geometry)
         output_width, output_height = config.process_size
         return output_frames, output_masks, output_width, output_height
 

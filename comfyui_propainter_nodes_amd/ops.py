@@ -74,8 +74,9 @@ def device_ints(values, device, dtype: torch.dtype = torch.int64) -> torch.Tenso
     key = (tuple(values), str(device), dtype)
     t = _INT_CACHE.get(key)
     if t is None:
-        if len(_INT_CACHE) > 4096:
-            _INT_CACHE.clear()
+        # never evicted: captured hipGraphs (graphs.py) bake in the addresses of the tensors handed out here, so a tensor
+        # must stay alive as long as any graph may replay it.  Entries are a few dozen bytes (window / frame id lists);
+        # 10^5 distinct lists are a few MB.
         t = _INT_CACHE[key] = torch.tensor(list(values), dtype=dtype, device=device)
     return t
 

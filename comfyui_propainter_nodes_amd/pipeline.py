@@ -209,7 +209,7 @@ def device_schedule(config: ProPainterConfig):
 
 def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, config: ProPainterConfig,
                    trace: dict | None = None, to_host: bool = True, frames_f32: torch.Tensor | None = None,
-                   sink=None) -> torch.Tensor:
+                   sink=None, static_masks=False) -> torch.Tensor:
     """uint8 arrays / tensors in ([T,H,W,3], [T,H,W], [T,H,W]) -> composed uint8 frames [T,H,W,3]
     (CPU tensor, or left in HBM when `to_host` is False).  `frames_f32` = the fp32 [-1,1] frames when the caller
     already produced them on the device (ops.frames_from_image).
@@ -217,6 +217,8 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     `sink` (optional): an object with `frames_final(comp, lo, hi)`, called as soon as frames [lo, hi) of the composed clip
     can no longer change (no later window has them as local frames) -- the node streams them to the host under the
     remaining windows (nodes._HostImageSink).
+    `static_masks`: True when every frame has the same masks (one MASK frame, outpaint borders), or a hashable key of the
+    outpaint geometry: the masked-window set of the transformer is then computed once per clip / once per geometry.
 
     = process_inpainting (:314-341) + feature_propagation (:228-311) of the reference."""
     dev = config.device
@@ -245,7 +247,7 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     packed = torch.empty(T, H, W, 8, device=dev, dtype=gen.dt)
     updated = torch.empty(T, H, W, 3, device=dev) if trace is not None else None
     ops.pack_encoder_input(frames, prop, md, upd, packed, updated)
-    st = gen.prepare_clip(packed, pred, md, upd)
+    st = gen.prepare_clip(packed, pred, md, upd, static_masks=static_masks)
     mark("encoder+clip_prep")
     comp = torch.zeros(T, H, W, 3, dtype=torch.uint8, device=dev)
     if trace is not None:

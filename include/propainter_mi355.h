@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 5
+#define PP_ABI_VERSION 6
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -69,6 +69,10 @@ int32_t pp_version(void);
 const char* pp_last_error(void);
 /* size in bytes of a parameter struct by name, for ABI self-checks */
 int64_t pp_struct_size(const char* name);
+/* The tuning / test knobs (PP_CONV_HALO, PP_CONV_HALO_CT, PP_CONV_KSPLIT, PP_CONV_TILE, PP_CONV_DIRECT, PP_CONV_TRACE:
+ * csrc/pp_options.h) are read from the environment once, at the first call that needs them; pp_reload_options() reads
+ * them again (tests that switch a kernel family inside one process).  No knob changes what an entry point computes. */
+void pp_reload_options(void);
 
 /* ------------------------------------------------------------------------------------
  * pp_conv2d -- implicit-GEMM convolution on MFMA (f16 inputs: 16x16x32; f32 inputs: 32x32x2 /

@@ -25,6 +25,29 @@ def pytest_configure(config):
 
 
 @pytest.fixture()
+def pp_knobs():
+    """Set PP_CONV_* knobs for ONE test inside this process: the library caches them at first use (csrc/pp_options.h), so
+    the environment is changed, the library told to read it again, and both are undone afterwards."""
+    from comfyui_propainter_nodes_amd import lib
+
+    saved = {}
+
+    def set_knobs(**kw):
+        for k, v in kw.items():
+            saved.setdefault(k, os.environ.get(k))
+            os.environ[k] = v
+        lib.reload_options()
+
+    yield set_knobs
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    lib.reload_options()
+
+
+@pytest.fixture()
 def emu_lib():
     """Build (if needed) and load the x86 emulation of the kernel sources. TEST ONLY."""
     import emu_loader

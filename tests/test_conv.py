@@ -44,8 +44,8 @@ CASES = [
     ("f32x2", 1, 21, 18, [64, 4], 64, (5, 1), 1, (2, 0), 1, 1, "tanh"),
     ("f32x2", 1, 10, 40, [32], 126, (2, 3), 1, (1, 0), 1, 2, None),
     ("f32x2", 1, 16, 32, [8], 40, 3, 1, 0, 1, 1, "leaky"),
-    # 16-row halo tiles, one wave per SIMD (PP_CONV_HALO_TALL=force): 128- and 96-channel tiles, 3x3 / 1x5 / 5x1, several
-    # chunks and segments (the double-buffered pixel tile and the 2-stage weight ring wrap), partial row / column tiles
+    # taller problems on the halo tiles: 128- and 96-channel tiles, 3x3 / 1x5 / 5x1, several chunks and segments (the
+    # weight ring wraps), partial row / column tiles
     ("f32x2", 1, 35, 20, [72], 128, 3, 1, 1, 1, 1, "tanh"),
     ("f32x2", 2, 18, 17, [32, 32], 256, (1, 5), 1, (0, 2), 1, 1, "sigmoid"),
     ("f32x2", 1, 20, 16, [36, 4], 100, (5, 1), 1, (2, 0), 1, 1, None),
@@ -77,7 +77,7 @@ def _ref_input(x, segC, groups):
 
 
 # ("xlforce" = the experimental 8-wave 256-channel tiles: emulator only until they have been measured on the MI355X)
-@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"), ("emu", "halo_rt"), ("emu", "tall"),
+@pytest.mark.parametrize("be,tile", [("emu", "large"), ("emu", "small"), ("emu", "xlforce"), ("emu", "tiny"), ("emu", "halo"), ("emu", "halo_rt"),
                                      ("emu", "ksplit"),
                                      pytest.param("hip", "large", marks=pytest.mark.gpu),
                                      pytest.param("hip", "small", marks=pytest.mark.gpu),
@@ -85,7 +85,6 @@ def _ref_input(x, segC, groups):
                                      pytest.param("hip", "tiny", marks=pytest.mark.gpu),
                                      pytest.param("hip", "halo", marks=pytest.mark.gpu),
                                      pytest.param("hip", "halo_rt", marks=pytest.mark.gpu),
-                                     pytest.param("hip", "tall", marks=pytest.mark.gpu),
                                      pytest.param("hip", "ksplit", marks=pytest.mark.gpu)])
 def test_conv2d_matches_torch(be, tile):
     """Every case on both tile families (128-pixel tiles / 32-pixel tiles for small problems).  The tile
@@ -103,9 +102,6 @@ def test_conv2d_matches_torch(be, tile):
     env = dict(os.environ, PP_CONV_TILE=tile, PP_TEST_BACKEND=be, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     env["PP_CONV_HALO"] = "0"      # the flat-tile kernels ...
     env["PP_CONV_KSPLIT"] = "0"
-    env["PP_CONV_HALO_TALL"] = "0"
-    if tile == "tall":             # ... 16-row halo tiles wherever they apply (3x3 / 1x5 / 5x1, Cout > 64), 8-row ones elsewhere
-        env.update(PP_CONV_TILE="large", PP_CONV_HALO="force", PP_CONV_HALO_TALL="force")
     if tile == "halo":             # ... or the halo-tile kernel for every eligible PP_F32X2 geometry, whatever its size
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
     if tile == "halo_rt":          # ... with the runtime-tap kernels also where a compile-time-tap form exists
@@ -179,10 +175,9 @@ def _run_case(backend, case):
 
 
 @pytest.mark.parametrize("family", ["flat", "halo", "ksplit"])
-def test_f16_conv_with_f32_output(backend, family, monkeypatch):
+def test_f16_conv_with_f32_output(backend, family, pp_knobs):
     """f16 operands, fp32 output (the deformable offsets / masks `om`) with a two-activation split, every kernel family."""
-    monkeypatch.setenv("PP_CONV_HALO", "force" if family == "halo" else "0")
-    monkeypatch.setenv("PP_CONV_KSPLIT", "force" if family == "ksplit" else "0")
+    pp_knobs(PP_CONV_HALO="force" if family == "halo" else "0", PP_CONV_KSPLIT="force" if family == "ksplit" else "0")
     g = torch.Generator().manual_seed(21)
     N, H, W, C, Cout = 1, 11, 19, 72, 136
     x = torch.randn(N, H, W, C, generator=g).half()
@@ -197,11 +192,11 @@ def test_f16_conv_with_f32_output(backend, family, monkeypatch):
 
 
 @pytest.mark.parametrize("halo", ["0", "force"])
-def test_f32x2_operand_range(backend, halo, monkeypatch):
+def test_f32x2_operand_range(backend, halo, pp_knobs):
     """PP_F32X2 at the edge of the f16 range (silent failure for |v| >= 32752).  The low term saturates:
     inputs up to 65504 stay within fp32-GEMM-like accuracy (absolute operand error <= 0.016), larger inputs saturate at
     +-65536 -- the result is finite, never Inf/NaN.  Both kernel families (flat 128-pixel tiles / halo tiles)."""
-    monkeypatch.setenv("PP_CONV_HALO", halo)
+    pp_knobs(PP_CONV_HALO=halo)
     g = torch.Generator().manual_seed(5)
     N, H, W, C, Cout = 1, 9, 17, 8, 40
     x = torch.randn(N, H, W, C, generator=g)
@@ -398,14 +393,14 @@ if __name__ == "__main__":  # child process of test_conv2d_matches_torch
         print("case", i, "ok", flush=True)
 
 
-def test_direct_small_cout_kernel(backend, monkeypatch):
+def test_direct_small_cout_kernel(backend, pp_knobs):
     """conv_direct.hip (at most 4 output channels, fp32 FMAs on the vector ALU) against float64 torch: the three layers it
     exists for (RAFT flow head 256 -> 2 with the in-place `coords += delta` epilogue, generator output 64 -> 3 tanh into a
     channel view, flow-completion output 32 -> 2) at sizes with partial 16 x 16 tiles and a partial 32-channel chunk, every
     weight packing (PP_F32X2 / f32 / f16), both output types, then seeded random epilogues."""
     import random
 
-    monkeypatch.setenv("PP_CONV_DIRECT", "force")
+    pp_knobs(PP_CONV_DIRECT="force")
     dev = backend
     g = torch.Generator().manual_seed(31)
     acts = {None: lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "sigmoid": torch.sigmoid, "tanh": torch.tanh}

@@ -11,9 +11,9 @@ from oracle import pipeline as OP
 
 
 @pytest.mark.slow
-def test_whole_pipeline_under_emulation_matches_oracle(emu_lib, monkeypatch):
+def test_whole_pipeline_under_emulation_matches_oracle(emu_lib, pp_knobs):
     # (the 1024-fiber split-K work-groups are slow to emulate and have their own tests: tests/test_conv.py)
-    monkeypatch.setenv("PP_CONV_KSPLIT", "0")
+    pp_knobs(PP_CONV_KSPLIT="0")
     T, H, W = 2, 128, 128
     image, mask = synth.synthetic_clip(T, H, W, 3)
     u8 = image_utils.image_to_uint8_frames(image)

@@ -142,3 +142,22 @@ def test_compose_u8_bit_exact(backend, dt):
         OP.compose_window(ref_comp, pred[..., :3].float().permute(0, 3, 1, 2), masks.float()[None, :, None],
                           [o.numpy() for o in orig], nb)
     assert np.array_equal(comp.cpu().numpy(), np.stack(ref_comp, 0))
+
+
+def test_static_mask_window_flags_are_one_constant_of_the_clip(backend):
+    """with one MASK frame replicated over the clip (or the border planes of an outpaint canvas) the
+    'window is masked' flags (sparse_transformer.py:321-326) do not depend on the window's local frames; the generator
+    computes them once per clip / geometry (generator.window_mask_flags) -- here: that constant equals the per-window
+    computation for every (first frame, count), and differs for a moving mask."""
+    dev = backend
+    g = torch.Generator().manual_seed(36)
+    fh, fw, T = 11, 20, 9
+    plane = (torch.rand(fh, fw, generator=g) > 0.93).to(torch.uint8)
+    static = plane[None].expand(T, -1, -1).contiguous().to(dev)
+    const = ops.window_flags(static, 0, 1, (5, 9)).cpu()
+    assert 0 < int(const.sum()) < const.numel()
+    for g0, lt in ((0, 5), (3, 6), (8, 1), (2, 7)):
+        assert torch.equal(ops.window_flags(static, g0, lt, (5, 9)).cpu(), const)
+    moving = static.clone()
+    moving[4:] = 0
+    assert not torch.equal(ops.window_flags(moving, 4, 3, (5, 9)).cpu(), const)
