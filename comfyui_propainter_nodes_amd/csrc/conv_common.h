@@ -42,6 +42,7 @@ struct ConvK {
   int act, act2, act_split;
   float act_param, out_scale;
   int epi;
+  int epi_from;  // the epilogue op applies to channels >= epi_from and reads aux1 / aux2 at channel c - epi_from
   const void* aux1;
   int aux1_ldc;
   int64_t aux1_zoff;
@@ -154,8 +155,8 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
     for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.act_param);
     if (p.out_scale != 0.f) v *= p.out_scale;
   }
-  if (p.epi != PP_EPI_NONE) {
-    const OT* s1 = e.aux1 + m * p.aux1_ldc + c;
+  if (p.epi != PP_EPI_NONE && c >= p.epi_from) {  // (epi_from % 4 == 0: no quad straddles it)
+    const OT* s1 = e.aux1 + m * p.aux1_ldc + (c - p.epi_from);
     const f4 a1 = load_quad(s1, full && quad_aligned(s1, p.aux1_ldc), nvalid);
     if (p.epi == PP_EPI_MUL_AUX1) {
       v *= a1;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
         v[r] = s > 0.f ? s : 0.f;
       }
     } else if (p.epi == PP_EPI_GRU) {
-      const OT* s2 = e.aux2 + m * p.aux2_ldc + c;
+      const OT* s2 = e.aux2 + m * p.aux2_ldc + (c - p.epi_from);
       const f4 h = load_quad(s2, full && quad_aligned(s2, p.aux2_ldc), nvalid);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (1.f - a1[r]) * h[r] + a1[r] * v[r];
@@ -257,8 +258,8 @@ __device__ __forceinline__ void store_quad_fast(const ConvK& p, const EpiCtx<OT>
     v = apply_act4(v, p.act, p.act_param);
     if (p.out_scale != 0.f) v *= p.out_scale;
   }
-  if (p.epi != PP_EPI_NONE) {
-    const f4 a1 = load_quad_vec(e.aux1 + m * p.aux1_ldc + c);
+  if (p.epi != PP_EPI_NONE && c >= p.epi_from) {
+    const f4 a1 = load_quad_vec(e.aux1 + m * p.aux1_ldc + (c - p.epi_from));
     if (p.epi == PP_EPI_MUL_AUX1) {
       v *= a1;
     } else if (p.epi == PP_EPI_ADD_AUX1) {
@@ -270,7 +271,7 @@ __device__ __forceinline__ void store_quad_fast(const ConvK& p, const EpiCtx<OT>
         v[r] = s > 0.f ? s : 0.f;
       }
     } else if (p.epi == PP_EPI_GRU) {
-      const f4 h = load_quad_vec(e.aux2 + m * p.aux2_ldc + c);
+      const f4 h = load_quad_vec(e.aux2 + m * p.aux2_ldc + (c - p.epi_from));
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (1.f - a1[r]) * h[r] + a1[r] * v[r];
     }

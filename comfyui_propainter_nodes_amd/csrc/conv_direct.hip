@@ -197,6 +197,7 @@ int launch_direct_small_cout(void* stream, const ConvK& k, int Z, int dtype, boo
   const int mode = options().direct;
   if (mode == 0) return 1;
   const bool force = mode == 2;
+  if (k.epi_from != 0) return 1;
   if (k.Cout > 4 || k.nseg != 1 || Z != 1 || k.sh != 1 || k.sw != 1 || k.dh != 1 || k.dw != 1 || k.pad_mode != PP_PAD_ZEROS) return 1;
   if (k.kh > 3 || k.kw > 3) return 1;
   if (k.Ho != k.H + 2 * k.ph - (k.kh - 1) || k.Wo != k.W + 2 * k.pw - (k.kw - 1)) return 1;

@@ -54,6 +54,9 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   k.act = p->act; k.act2 = p->act2; k.act_split = p->act_split;
   k.act_param = p->act_param; k.out_scale = p->out_scale;
   k.epi = p->epi;
+  if (p->epi_from < 0 || (p->epi_from & 3) != 0 || (p->epi_from != 0 && p->epi_from >= p->Cout))
+    return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: epi_from must be a multiple of 4 below Cout");
+  k.epi_from = p->epi == PP_EPI_NONE ? 0 : (int)p->epi_from;
   k.aux1 = p->aux1; k.aux1_ldc = (int)p->aux1_ldc; k.aux1_zoff = p->aux1_zoff;
   k.aux2 = p->aux2; k.aux2_ldc = (int)p->aux2_ldc; k.aux2_zoff = p->aux2_zoff;
   k.pre_add = p->pre_add; k.pre_add_ldc = (int)p->pre_add_ldc;

@@ -239,7 +239,7 @@ def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, 
 
 
 def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
-           act2=None, act_split=0, out_scale=0.0, epi=None, aux1=None, aux2=None, pre_add=None,
+           act2=None, act_split=0, out_scale=0.0, epi=None, aux1=None, aux2=None, pre_add=None, epi_from=0,
            in_zoff: list[int] | None = None, out_zoff: int | None = None) -> torch.Tensor:
     """Launch pp_conv2d.  `inputs` are channels-last views (the K segments), `out` a
     channels-last view `[N, Ho, Wo, >=Cout*groups]` that receives the result."""
@@ -292,6 +292,7 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
     P.act_param = act_param
     P.out_scale = out_scale
     P.epi = EPI[epi]
+    P.epi_from = epi_from
     if aux1 is not None:
         if aux1.dtype != out.dtype:
             raise TypeError("aux1 dtype must match out dtype")

@@ -147,13 +147,17 @@ class RaftFlow:
         # GRU input = cat(h, inp, motion) (update.py:60-71).  `inp` (the context features) does not change over
         # the iterations, so its third of every GRU convolution is computed ONCE per clip and enters the
         # per-iteration convolution over [h | motion] as a pre-activation addend (exact, 1/3 fewer GRU FLOPs).
+        # The z and r gates read the same input (update.py:41-43 / :49-51): ONE 256-channel convolution computes both
+        # (r03; sigmoid on all channels, the r * h product as an epilogue on channels 128..255 only: `epi_from`), its two
+        # 128-channel tiles of a pixel tile run next to each other and share the pixel stage in L2.
         self.gru, self.gru_ctx = {}, {}
-        for g in "zrq":
-            for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
-                w, b = u[f"gru.conv{g}{sfx}.weight"], u[f"gru.conv{g}{sfx}.bias"]
+        for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
+            ws = {g: u[f"gru.conv{g}{sfx}.weight"] for g in "zrq"}
+            bs = {g: u[f"gru.conv{g}{sfx}.bias"] for g in "zrq"}
+            for key, w, b in (("zr", torch.cat([ws["z"], ws["r"]], 0), torch.cat([bs["z"], bs["r"]], 0)), ("q", ws["q"], bs["q"])):
                 w_dyn = torch.cat([w[:, 0:128], w[:, 256:384]], 1)
-                self.gru[g + sfx] = _conv_spec(w_dyn, b, dt, padding=pad, seg_channels=[128, 128]).to(device)
-                self.gru_ctx[g + sfx] = _conv_spec(w[:, 128:256].contiguous(), None, dt, padding=pad).to(device)
+                self.gru[key + sfx] = _conv_spec(w_dyn, b, dt, padding=pad, seg_channels=[128, 128]).to(device)
+                self.gru_ctx[key + sfx] = _conv_spec(w[:, 128:256].contiguous(), None, dt, padding=pad).to(device)
         self.fh1 = spec("flow_head.conv1", padding=1)
         self.fh2 = spec("flow_head.conv2", padding=1)
         self.mask0 = spec("mask.0", padding=1)
@@ -200,12 +204,12 @@ class RaftFlow:
         hcur = ctx[..., 0:128]
         hA = torch.empty(P, h, w, 128, device=dev)
         hB = torch.empty(P, h, w, 128, device=dev)
-        z = torch.empty(P, h, w, 128, device=dev)
-        rh = torch.empty(P, h, w, 128, device=dev)
+        zr = torch.empty(P, h, w, 256, device=dev)      # z (128) | r * h (128)
+        z, rh = zr[..., 0:128], zr[..., 128:256]
         t256 = torch.empty(P, h, w, 256, device=dev)
         ctx_term = {}
         for key, sp in self.gru_ctx.items():
-            ctx_term[key] = ops.conv2d(sp, [inp], torch.empty(P, h, w, 128, device=dev))
+            ctx_term[key] = ops.conv2d(sp, [inp], torch.empty(P, h, w, sp.cout, device=dev))
         for it in range(iters):
             ops.corr_lookup(pyr, flow, corr)
             if trace is not None and it == 0:
@@ -218,8 +222,8 @@ class RaftFlow:
             ops.conv2d(self.conv, [cf], mf[..., 0:126], act="relu")
             for sfx, hout in (("1", hA), ("2", hB)):
                 segs = [hcur, mf]
-                ops.conv2d(self.gru["z" + sfx], segs, z, act="sigmoid", pre_add=ctx_term["z" + sfx])
-                ops.conv2d(self.gru["r" + sfx], segs, rh, act="sigmoid", epi="mul", aux1=hcur, pre_add=ctx_term["r" + sfx])
+                ops.conv2d(self.gru["zr" + sfx], segs, zr, act="sigmoid", epi="mul", aux1=hcur, epi_from=128,
+                           pre_add=ctx_term["zr" + sfx])
                 ops.conv2d(self.gru["q" + sfx], [rh, mf], hout, act="tanh", epi="gru", aux1=z, aux2=hcur,
                            pre_add=ctx_term["q" + sfx])
                 hcur = hout

@@ -128,6 +128,9 @@ typedef struct {
   const void* pre_add; /* optional [N][Ho][Wo][Cout] (out dtype) added BEFORE the activation: a partial
                           convolution over constant input channels computed once (RAFT GRU context term) */
   int64_t pre_add_ldc;
+  int64_t epi_from;    /* (ABI v6) the epilogue op applies to output channels >= epi_from only, and reads aux1 / aux2 at
+                          channel (c - epi_from); multiple of 4; 0 = all channels.  RAFT's GRU computes z and r in ONE
+                          256-channel convolution: sigmoid on all, r * h (PP_EPI_MUL_AUX1) on channels 128..255 */
   const void* weight_f32; /* optional (ABI v5), only read when Cout <= 4: the same weights as fp32
                              [tap][32-channel chunk][Cout padded to 2 or 4][32] for the vector-ALU kernel of the 2-3
                              channel layers (conv_direct.hip reads them through the scalar cache instead of decoding

@@ -192,6 +192,44 @@ def test_f16_conv_with_f32_output(backend, family, pp_knobs):
 
 
 @pytest.mark.parametrize("halo", ["0", "force"])
+def test_epilogue_from_a_channel(backend, halo, pp_knobs):
+    """`epi_from` (ABI v6): RAFT's GRU computes the z and r gates (update.py:41-43) in ONE 256-channel PP_F32X2 convolution
+    over [h | motion] -- sigmoid on all channels, r * h (PP_EPI_MUL_AUX1) on channels 128..255 only, read at channel
+    c - 128 of `h` -- into one buffer whose halves the q convolution then uses as views.  1x5 taps, a context pre-addend,
+    partial tiles; flat and halo kernel families; plus the GRU blend epilogue from channel 64 on."""
+    pp_knobs(PP_CONV_HALO=halo)
+    g = torch.Generator().manual_seed(23)
+    N, H, W = 2, 9, 21
+    h = torch.randn(N, H, W, 128, generator=g)
+    mf = torch.randn(N, H, W, 128, generator=g)
+    w = torch.randn(256, 256, 1, 5, generator=g) * 0.03
+    b = torch.randn(256, generator=g) * 0.1
+    pre = torch.randn(N, H, W, 256, generator=g) * 0.2
+    spec = ops.make_conv_spec(w, b, torch.float32, padding=(0, 2), seg_channels=[128, 128], split=True).to(backend)
+    zr = torch.empty(N, H, W, 256, device=backend)
+    ops.conv2d(spec, [h.to(backend), mf.to(backend)], zr, act="sigmoid", epi="mul", aux1=h.to(backend), epi_from=128,
+               pre_add=pre.to(backend))
+    x = torch.cat([h, mf], -1).permute(0, 3, 1, 2).double()
+    lin = F.conv2d(x, w.double(), b.double(), padding=(0, 2)).permute(0, 2, 3, 1) + pre.double()
+    ref = torch.sigmoid(lin)
+    ref[..., 128:] = ref[..., 128:] * h.double()
+    assert (zr.double().cpu() - ref).abs().max().item() < 2e-5
+    # GRU blend from channel 64 on: y = (1 - z) * h + z * v for c >= 64, plain tanh below
+    z = torch.rand(N, H, W, 64, generator=g)
+    hh = torch.randn(N, H, W, 64, generator=g)
+    w2 = torch.randn(128, 256, 1, 5, generator=g) * 0.03
+    spec2 = ops.make_conv_spec(w2, None, torch.float32, padding=(0, 2), seg_channels=[128, 128], split=True).to(backend)
+    out = torch.empty(N, H, W, 128, device=backend)
+    ops.conv2d(spec2, [h.to(backend), mf.to(backend)], out, act="tanh", epi="gru", aux1=z.to(backend), aux2=hh.to(backend), epi_from=64)
+    v = torch.tanh(F.conv2d(x, w2.double(), None, padding=(0, 2)).permute(0, 2, 3, 1))
+    ref2 = v.clone()
+    ref2[..., 64:] = (1 - z.double()) * hh.double() + z.double() * v[..., 64:]
+    assert (out.double().cpu() - ref2).abs().max().item() < 2e-5
+    with pytest.raises(RuntimeError):
+        ops.conv2d(spec2, [h.to(backend), mf.to(backend)], out, act="tanh", epi="gru", aux1=z.to(backend), aux2=hh.to(backend), epi_from=62)
+
+
+@pytest.mark.parametrize("halo", ["0", "force"])
 def test_f32x2_operand_range(backend, halo, pp_knobs):
     """PP_F32X2 at the edge of the f16 range (silent failure for |v| >= 32752).  The low term saturates:
     inputs up to 65504 stay within fp32-GEMM-like accuracy (absolute operand error <= 0.016), larger inputs saturate at

@@ -41,8 +41,9 @@ image, mask = synth.synthetic_clip(C["T"], C["H"], C["W"], 1234)
 node = nodes.ProPainterInpaint()
 args = (image, mask, C["W"], C["H"], C["mask_dilates"], C["flow_mask_dilates"], C["ref_stride"], C["neighbor_length"],
         C["subvideo_length"], C["raft_iter"], "enable")
-for mode in ("stream", "host", "device"):
-    os.environ["PP_OUTPUT"] = mode
+for mode in ("stream", "stream-sync", "host", "device"):
+    os.environ["PP_OUTPUT"] = mode.split("-")[0]
+    nodes._HostImageSink.wait_mode = "sync" if mode.endswith("sync") else "poll"
     nodes._Timer.collect = False
     t = best(lambda: node.propainter_inpainting(*args))
     nodes._Timer.collect = True

@@ -14,6 +14,10 @@ from comfyui_propainter_nodes_amd import image_utils, lib, nodes, pipeline, synt
 CONFIGS = {
     2: dict(T=80, H=360, W=640, nl=10, rs=10, sv=80, iters=20, outpaint=None),
     3: dict(T=80, H=360, W=640, nl=10, rs=10, sv=80, iters=20, outpaint=(1.2, 1.0)),
+    # configs[3]: the 640-frame clip of the 8-GPU run, here on ONE GPU: as one process (8 sub-videos one after the other)
+    # and as 8 in-process virtual ranks driving the sharded code path (distributed.run_simulated); the two results must
+    # be identical (--virtual-ranks N)
+    4: dict(T=640, H=360, W=640, nl=10, rs=10, sv=80, iters=20, outpaint=None),
     5: dict(T=160, H=720, W=1280, nl=20, rs=10, sv=80, iters=20, outpaint=None),
 }
 
@@ -24,6 +28,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--size", type=str, default="")
+    ap.add_argument("--virtual-ranks", type=int, default=0, help="also run the sharded driver with N in-process ranks and compare")
     a = ap.parse_args()
     c = dict(CONFIGS[a.config])
     if a.frames:
@@ -56,6 +61,23 @@ def main():
         print(json.dumps({"config": a.config, "frames": c["T"], "size": list(size), "seconds": round(dt, 3),
                           "frames_per_s": round(c["T"] / dt, 2), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
                           "out_mean": float(out.float().mean())}), flush=True)
+    if a.virtual_ranks:
+        from comfyui_propainter_nodes_amd import distributed as D
+
+        os.environ["PP_TIMING"] = "0"
+        os.environ["PP_GRAPHS"] = "0"   # virtual ranks share one model object (and its captured graphs' static buffers)
+        single = pipeline.run_inpainting(*args, to_host=False)
+        torch.cuda.reset_peak_memory_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = D.run_simulated(lambda r: D.GpuBackend(models, cfg), a.virtual_ranks, cfg, *args[1:4])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        same = [bool(torch.equal(r, single)) for r in res]
+        diff = max(int((r.int() - single.int()).abs().max()) for r in res)
+        print(json.dumps({"config": a.config, "virtual_ranks": a.virtual_ranks, "frames": c["T"], "seconds_all_ranks_serialised": round(dt, 3),
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                          "every_rank_bit_identical_to_single_process": all(same), "max_abs_diff_u8": diff}), flush=True)
 
 
 if __name__ == "__main__":
