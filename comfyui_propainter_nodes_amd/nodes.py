@@ -102,11 +102,11 @@ def _expand_masks(m: torch.Tensor, T: int) -> torch.Tensor:
 def _output(comp_u8: torch.Tensor, fm_u8: torch.Tensor, md_u8: torch.Tensor):
     """handle_output (image_utils.py:276-290): IMAGE fp32 k/255 on the host, the two masks fp32 on the device.
     The uint8 frames cross PCIe (a quarter of the fp32 bytes) and become float32(k) / 255 on the host cores (the same
-    IEEE division as the reference's numpy expression); PP_OUTPUT=device converts on the GPU and copies fp32 instead.
-    (Default on a GPU: PP_OUTPUT=stream, the same host arithmetic streamed under the window loop by _HostImageSink;
-    PP_OUTPUT=host selects this function's blocking form.)"""
-    if os.environ.get("PP_OUTPUT") == "device":
-        images = ops.image_from_u8(comp_u8).cpu()
+    IEEE division as the reference's numpy expression); PP_OUTPUT=device (the default, r03) converts on the GPU and copies fp32 instead.
+    (PP_OUTPUT=host selects the uint8 D2H + host conversion of this function; PP_OUTPUT=stream the same host arithmetic
+    streamed under the window loop by _HostImageSink -- slower end to end on the r03 box, see _run.)"""
+    if os.environ.get("PP_OUTPUT", "device") == "device" and comp_u8.is_cuda:
+        images = ops.image_from_u8(comp_u8).cpu()      # float32(k) / 255 on the GPU: the same IEEE division, bit-identical
     else:
         images = comp_u8.cpu().to(torch.float32).div_(255.0)
     return images, fm_u8.float().squeeze(), md_u8.float().squeeze()
@@ -215,7 +215,10 @@ TRACE: dict | None = None  # debugging / test aid: when a dict, the next node ca
 def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer, static_masks=False):
     if TRACE is not None:
         TRACE.update(frames_u8=fr_u8, flow_masks=fm, masks_dilated=md)
-    stream_out = fr_u8.is_cuda and os.environ.get("PP_OUTPUT", "stream") == "stream" and TRACE is None
+    # (r03: measured on the MI355X box, node call of the 80-frame clip: PP_OUTPUT=device 452 ms, host 466 ms, stream 496 ms --
+    # with the streaming sink the pipeline itself ran 58 ms longer, whichever way its worker waits for the copies;
+    # tools/node_gap.py.  The default is therefore the GPU conversion + one D2H; the sink stays selectable.)
+    stream_out = fr_u8.is_cuda and os.environ.get("PP_OUTPUT", "device") == "stream" and TRACE is None
     sink = _HostImageSink(*fr_u8.shape[:3], fr_u8.device) if stream_out else None
     try:
         comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32, sink=sink,

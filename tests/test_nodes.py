@@ -60,11 +60,12 @@ def test_streamed_output_equals_blocking_output(seeded_models, monkeypatch):
     kw = dict(image=image, mask=mask, width=144, height=128, mask_dilates=3, flow_mask_dilates=4, fp16="enable", raft_iter=2,
               neighbor_length=4, ref_stride=3, subvideo_length=80)
     outs = {}
-    for mode in ("host", "stream", "stream"):
+    for mode in ("host", "device", "stream", "stream"):
         monkeypatch.setenv("PP_OUTPUT", mode)
         outs.setdefault(mode, []).append(getattr(node, node.FUNCTION)(**kw)[0].clone())
     assert outs["host"][0].dtype == torch.float32 and not outs["stream"][0].is_cuda
     assert torch.equal(outs["host"][0], outs["stream"][0]) and torch.equal(outs["host"][0], outs["stream"][1])
+    assert torch.equal(outs["host"][0], outs["device"][0])    # float32(k) / 255 on the GPU (the r03 default) is the same division
 
 
 @pytest.mark.gpu

@@ -59,7 +59,7 @@ def test_raft_split_gemm_matches_exact_f32_gemm(hip_lib, monkeypatch):
     fe, be = exact(frames, 6)
     monkeypatch.setenv("PP_F32_GEMM", "split")
     split = raft.RaftFlow(sds["raft"], "cuda:0")
-    assert split.convc1.split and split.gru["z1"].split
+    assert split.convc1.split and split.gru["zr1"].split
     fs, bs = split(frames, 6)
     assert torch.isfinite(fs).all() and torch.isfinite(bs).all()
     assert (fs - fe).abs().max().item() < 1e-3, (fs - fe).abs().max().item()

@@ -17,5 +17,5 @@ python tools/make_traffic.py $O/pmc_fetch_size.json $O/pmc_write_size.json $O/tr
   conv_igemm_kernelIDF16_=f16 conv_halo_f16_kernel=f16 conv_halo_f16_ct_kernel=f16 conv_ksplit_kernel=f16 'conv_igemm_kernel<float'=f32 > /dev/null
 cp $O/traffic.json profiles/${TAG}_traffic.json   # bench.py reads the newest profiles/r*_traffic.json for roofline.traffic
 timeout 400 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
-PP_OUTPUT=device timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_output_device.json 2>> $O/bench.err
-head -14 $O/kernel_stats.md | cut -c1-160; tail -c 700 $O/bench.json; tail -c 400 $O/bench_output_device.json
+PP_OUTPUT=stream timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_output_stream.json 2>> $O/bench.err
+head -14 $O/kernel_stats.md | cut -c1-160; tail -c 700 $O/bench.json; tail -c 400 $O/bench_output_stream.json
