@@ -276,16 +276,38 @@ __global__ void __launch_bounds__(256) instnorm_apply4_kernel(const float* __res
 // ----------------------------------------------------------------------------------------
 // 2x2 average pooling of the correlation planes
 // ----------------------------------------------------------------------------------------
+// planes are row-major [H][W] or tiled [ceil(H/4)][ceil(W/8)][4][8] (128-byte tiles, see pp_corr_lookup)
+__device__ __forceinline__ int64_t plane_pitch(int H, int W, int tiled) {
+  return tiled ? (int64_t)((H + 3) >> 2) * ((W + 7) >> 3) * 32 : (int64_t)H * W;
+}
+__device__ __forceinline__ int plane_off(int y, int x, int W, int tiled) {
+  return tiled ? (((y >> 2) * ((W + 7) >> 3) + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7) : y * W + x;
+}
+
 __global__ void __launch_bounds__(256) avgpool2x2_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                         int H, int W, int Ho, int Wo, int64_t total) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int xo = (int)(idx % Wo);
-  const int64_t t = idx / Wo;
-  const int yo = (int)(t % Ho);
-  const int64_t b = t / Ho;
-  const float* src = in + (b * H + 2 * yo) * W + 2 * xo;
-  out[idx] = (src[0] + src[1] + src[W] + src[W + 1]) * 0.25f;
+                                                         int H, int W, int Ho, int Wo, int in_tiled, int out_tiled,
+                                                         int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B * (output plane pitch): consecutive threads
+  if (idx >= total) return;                                      // write consecutive floats in either layout
+  const int64_t opitch = plane_pitch(Ho, Wo, out_tiled);
+  const int64_t b = idx / opitch;
+  const int r = (int)(idx - b * opitch);
+  int yo, xo;
+  if (out_tiled) {
+    const int tw = (Wo + 7) >> 3, tile = r >> 5;
+    yo = ((tile / tw) << 2) + ((r >> 3) & 3);
+    xo = ((tile % tw) << 3) + (r & 7);
+  } else {
+    yo = r / Wo;
+    xo = r - yo * Wo;
+  }
+  float v = 0.f;  // the padding of a tiled plane is zero
+  if (yo < Ho && xo < Wo) {
+    const float* src = in + b * plane_pitch(H, W, in_tiled);
+    v = (src[plane_off(2 * yo, 2 * xo, W, in_tiled)] + src[plane_off(2 * yo, 2 * xo + 1, W, in_tiled)] +
+         src[plane_off(2 * yo + 1, 2 * xo, W, in_tiled)] + src[plane_off(2 * yo + 1, 2 * xo + 1, W, in_tiled)]) * 0.25f;
+  }
+  out[idx] = v;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -295,6 +317,7 @@ struct LookupK {
   const float* pyr[4];
   int ph[4];
   int pw[4];
+  int tiled[4];
   const float* flow;
   int flow_ldc;
   float* out;
@@ -335,7 +358,8 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
     ox[lvl] = (int)floorf(bx) - 5;
     oy[lvl] = (int)floorf(by) - 5;
     const int H = k.ph[lvl], W = k.pw[lvl];
-    const float* plane = k.pyr[lvl] + pc * (int64_t)H * W;
+    const int tl = k.tiled[lvl];
+    const float* plane = k.pyr[lvl] + pc * plane_pitch(H, W, tl);
 #pragma unroll
     for (int it = 0; it < (kCorrLvl + 63) / 64; ++it) {
       const int idx = lane + it * 64;
@@ -343,7 +367,7 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
         const int r = idx / kCorrWin, c = idx - r * kCorrWin;
         const int y = oy[lvl] + r, x = ox[lvl] + c;
         const bool in = active && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        mywin[lvl * kCorrLvl + idx] = in ? plane[(int64_t)y * W + x] : 0.f;
+        mywin[lvl * kCorrLvl + idx] = in ? plane[plane_off(y, x, W, tl)] : 0.f;
       }
     }
   }
@@ -505,10 +529,11 @@ extern "C" int32_t pp_avgpool2x2(void* stream, const pp_avgpool2x2_params* p) {
   using namespace pp;
   if (!p || !p->in || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_avgpool2x2: null argument");
   const int Ho = (int)(p->H / 2), Wo = (int)(p->W / 2);
-  const int64_t total = p->B * Ho * Wo;
-  if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_avgpool2x2: empty problem");
+  if (Ho <= 0 || Wo <= 0 || p->B <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_avgpool2x2: empty problem");
+  const int64_t opitch = p->out_tiled ? (int64_t)((Ho + 3) / 4) * ((Wo + 7) / 8) * 32 : (int64_t)Ho * Wo;
+  const int64_t total = p->B * opitch;
   PP_LAUNCH(avgpool2x2_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, (const float*)p->in, (float*)p->out,
-            (int)p->H, (int)p->W, Ho, Wo, total);
+            (int)p->H, (int)p->W, Ho, Wo, (int)p->in_tiled, (int)p->out_tiled, total);
   return pp_check_launch("pp_avgpool2x2");
 }
 
@@ -522,6 +547,7 @@ extern "C" int32_t pp_corr_lookup(void* stream, const pp_corr_lookup_params* p) 
     k.pyr[l] = (const float*)p->pyr[l];
     k.ph[l] = (int)p->ph[l];
     k.pw[l] = (int)p->pw[l];
+    k.tiled[l] = (int)p->tiled[l];
   }
   k.flow = (const float*)p->flow;
   k.flow_ldc = (int)p->flow_ldc;

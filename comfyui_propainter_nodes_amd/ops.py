@@ -436,35 +436,66 @@ def instnorm(x: torch.Tensor, y: torch.Tensor, *, relu_pre=False, relu_post=Fals
     return y
 
 
-def avgpool2x2(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """x [B,H,W] fp32 dense -> out [B,H//2,W//2]."""
+def tiled_pitch(h: int, w: int) -> int:
+    """Floats of an h x w correlation plane stored in 4 x 8 tiles of 128 bytes (pp_corr_lookup)."""
+    return -(-h // 4) * -(-w // 8) * 32
+
+
+def tiled_order(h: int, w: int) -> list[int]:
+    """Source pixel (y*w + x) of every position of a tiled h x w plane; the zero padding is index h*w."""
+    th, tw = -(-h // 4), -(-w // 8)
+    out = []
+    for ty in range(th):
+        for tx in range(tw):
+            for r in range(4):
+                for c in range(8):
+                    y, x = 4 * ty + r, 8 * tx + c
+                    out.append(y * w + x if y < h and x < w else h * w)
+    return out
+
+
+def avgpool2x2(x: torch.Tensor, out: torch.Tensor, hw: tuple[int, int] | None = None, in_tiled: bool = False,
+               out_tiled: bool = False) -> torch.Tensor:
+    """x [B,H,W] fp32 dense -> out [B,H//2,W//2]; with `hw` = (H, W) the planes are flat [B, pitch] tensors in the
+    row-major or the tiled layout (in_tiled / out_tiled; tiled_pitch())."""
     check_device(x, out)
-    b, h, w = x.shape
-    if not x.is_contiguous() or not out.is_contiguous() or tuple(out.shape) != (b, h // 2, w // 2):
+    if hw is None:
+        b, h, w = x.shape
+        ok = tuple(out.shape) == (b, h // 2, w // 2)
+    else:
+        h, w = hw
+        b = x.shape[0]
+        ok = (x.numel() == b * (tiled_pitch(h, w) if in_tiled else h * w)
+              and out.numel() == b * (tiled_pitch(h // 2, w // 2) if out_tiled else (h // 2) * (w // 2)))
+    if not x.is_contiguous() or not out.is_contiguous() or not ok:
         raise ValueError("avgpool2x2: bad shapes")
     P = _lib.STRUCTS["pp_avgpool2x2_params"]()
     setattr(P, "in", x.data_ptr())
     P.out, P.B, P.H, P.W = out.data_ptr(), b, h, w
+    P.in_tiled, P.out_tiled = int(in_tiled), int(out_tiled)
     _call("pp_avgpool2x2", out, P)
     return out
 
 
-def corr_lookup(pyramid: list[torch.Tensor], flow: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """pyramid[l]: [N, h*w, h_l, w_l] fp32; flow [N,h,w,2] view; out [N,h,w,324] view."""
-    check_device(*pyramid, flow, out)
+def corr_lookup(pyramid: list, flow: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """pyramid[l]: [N, h*w, h_l, w_l] fp32 (row-major planes) or a tuple (flat [N, h*w, pitch] tensor, h_l, w_l, tiled);
+    flow [N,h,w,2] view; out [N,h,w,324] view."""
+    levels = [(t, t.shape[2], t.shape[3], False) if torch.is_tensor(t) else t for t in pyramid]
+    check_device(*[t for t, _, _, _ in levels], flow, out)
     n, h, w, _, fl = nhwc_view(flow)
     P = _lib.STRUCTS["pp_corr_lookup_params"]()
-    for l, t in enumerate(pyramid):
-        if not t.is_contiguous() or t.shape[0] != n or t.shape[1] != h * w:
+    for l, (t, ph, pw, tiled) in enumerate(levels):
+        pitch = tiled_pitch(ph, pw) if tiled else ph * pw
+        if not t.is_contiguous() or t.shape[0] != n or t.numel() != n * h * w * pitch:
             raise ValueError("corr_lookup: bad pyramid level")
-        P.pyr[l], P.ph[l], P.pw[l] = t.data_ptr(), t.shape[2], t.shape[3]
+        P.pyr[l], P.ph[l], P.pw[l], P.tiled[l] = t.data_ptr(), ph, pw, int(tiled)
     P.flow, P.flow_ldc = flow.data_ptr(), fl
     P.out, P.out_ldc = out.data_ptr(), nhwc_view(out)[4]
     P.N, P.h, P.w = n, h, w
     if CONV_PROFILE is not None and out.is_cuda:
         # algorithmic bytes (SURVEY.md 8d): per pixel the 10x10 fp32 footprint of the 9x9 bilinear samples on each level
         # + the 324 fp32 outputs
-        nbytes = float(n * h * w) * (len(pyramid) * 100 * 4 + 324 * 4)
+        nbytes = float(n * h * w) * (len(levels) * 100 * 4 + 324 * 4)
         CONV_PROFILE.launch("corr_lookup", 0.0, lambda: _call("pp_corr_lookup", out, P), nbytes)
     else:
         _call("pp_corr_lookup", out, P)

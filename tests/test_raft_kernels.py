@@ -67,6 +67,24 @@ def test_pyramid_lookup_upsample(backend):
     coords = OR.coords_grid(n, h, w) + flow.permute(0, 3, 1, 2)
     ref = OR.corr_lookup(pyr_ref, coords).permute(0, 2, 3, 1)
     assert torch.allclose(out.cpu(), ref, atol=2e-5)
+    # the same pyramid with levels 0 and 1 in 4 x 8 tiles (r03 layout; 18 columns -> 3 tile columns with padding, 16 rows ->
+    # 4 tile rows; level 1: 8 x 9 -> 2 x 2 tiles): pooled tiled -> tiled -> row-major, and an identical lookup, bit for bit
+    order = torch.tensor(ops.tiled_order(h, w))
+    volz = torch.cat([vol.cpu().view(n, h * w, h * w), torch.zeros(n, h * w, 1)], 2)
+    t0 = volz.index_select(2, order).contiguous().to(dev)                    # [n, hw, tiled pitch]
+    tp = [(t0, h, w, True)]
+    for lvl in range(1, 4):
+        _, hi, wi, ti = tp[-1]
+        ho, wo, to = hi // 2, wi // 2, lvl == 1
+        nxt = torch.empty(n, h * w, ops.tiled_pitch(ho, wo) if to else ho * wo, device=dev)
+        ops.avgpool2x2(tp[-1][0].view(n * h * w, -1), nxt.view(n * h * w, -1), hw=(hi, wi), in_tiled=ti, out_tiled=to)
+        tp.append((nxt, ho, wo, to))
+    o1 = torch.tensor(ops.tiled_order(h // 2, w // 2))
+    lvl1 = torch.cat([pyr[1].cpu().view(n, h * w, -1), torch.zeros(n, h * w, 1)], 2).index_select(2, o1)
+    assert torch.equal(tp[1][0].cpu(), lvl1) and torch.equal(tp[2][0].cpu().view(-1), pyr[2].cpu().view(-1))
+    out_t = torch.empty(n, h, w, 324, device=dev)
+    ops.corr_lookup(tp, buf[..., 6:8], out_t)
+    assert torch.equal(out_t.cpu(), out.cpu())
     # convex upsampling
     mask = torch.randn(n, h, w, 576, generator=g)
     up = torch.empty(n, 8 * h, 8 * w, 2, device=dev)
