@@ -325,6 +325,7 @@ def main():
     traffic = None
     tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
     tfile = tfiles[-1] if tfiles else ROOT / "profiles" / "none"
+    fam = {}
     if tfile.exists():  # PMC passes cannot run inside bench.py: the committed rocprofv3 result of the same kernel
         fam = json.loads(tfile.read_text()).get("families", {})
         if dom in fam:
@@ -346,14 +347,16 @@ def main():
             roofline["attention"] = {"kernel": "window_attention_f16_kernel (pp_window_attention)", "bound": "mfma",
                                      "achieved": round(tf, 1), "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["f16"], 4),
                                      "launches": v["n"], "avg_launch_us": round(v["ms"] * 1e3 / v["n"], 1), "share_of_step_ms": round(v["ms"], 1),
-                                     "flops_per_launch": v["flops"] / v["n"], "algorithmic_bytes_per_launch": v["bytes"] / v["n"]}
+                                     "flops_per_launch": v["flops"] / v["n"], "algorithmic_bytes_per_launch": v["bytes"] / v["n"],
+                                     "traffic": fam.get("attention", {}).get("hbm_bytes_per_launch")}
         if "corr_lookup" in prof:  # north_star: achieved HBM GB/s of the correlation lookup
             v = prof["corr_lookup"]
             gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             roofline["corr_lookup"] = {"kernel": "corr_lookup_kernel (pp_corr_lookup)", "bound": "hbm", "achieved": round(gbs, 1),
                                        "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "launches": v["n"],
                                        "avg_launch_us": round(v["ms"] * 1e3 / v["n"], 1), "share_of_step_ms": round(v["ms"], 1),
-                                       "algorithmic_bytes_per_launch": v["bytes"] / v["n"]}
+                                       "algorithmic_bytes_per_launch": v["bytes"] / v["n"],
+                                       "traffic": fam.get("corr_lookup", {}).get("hbm_bytes_per_launch")}
 
     line = {
         "metric": "inpainted frames/sec end-to-end, 640x360 neighbor=10", "value": round(fps, 3), "unit": "frames/s",
