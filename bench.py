@@ -288,8 +288,8 @@ def main():
     else:
         fr_d = torch.from_numpy(frames_u8).to(dev)
 
-        def step():
-            return pipeline.run_inpainting(models, fr_d, fm_d, md_d, cfg, to_host=False)
+        def step():   # (one MASK frame replicated over the clip, as the node sees it: static_masks)
+            return pipeline.run_inpainting(models, fr_d, fm_d, md_d, cfg, to_host=False, static_masks=True)
 
     for _ in range(args.warmup):
         step()

@@ -327,16 +327,18 @@ struct LookupK {
 };
 
 // One wave per (pair, pixel).  The 9x9 bilinear samples of a level touch a 10x10 window of that pixel's correlation
-// plane; the wave first copies a 12x12 window per level (one more row / column each side: the reference's normalise ->
-// unnormalise round trip can move a coordinate across an integer by a few ulps) into LDS with row-contiguous loads
-// -- 576 floats, 9 independent loads per lane, all in flight together -- then every lane evaluates 5-6 of the 324
-// outputs from LDS with the reference's arithmetic and the wave writes 324 contiguous floats.  The previous kernel issued
-// four scattered 4-byte loads per OUTPUT (1296 per pixel instead of 576, no reuse of the window).
-constexpr int kCorrWin = 12;
-constexpr int kCorrLvl = kCorrWin * kCorrWin;
+// plane; the wave first copies a 12-row window per level (one more row / column each side: the reference's normalise ->
+// unnormalise round trip can move a coordinate across an integer by a few ulps) into LDS, then every lane evaluates 5-6 of
+// the 324 outputs from LDS with the reference's arithmetic and the wave writes 324 contiguous floats.
+// r03: the window is copied as 16-byte pieces -- its columns start at the 4-aligned x below the window's first column and
+// span 16 (12 rows x 4 pieces = 48 lanes, ONE load instruction per level) -- on the levels whose rows allow it (4 x 8
+// tiled planes, whose zero padding doubles as the out-of-plane value; row-major planes with W % 4 == 0); the 5 x 10 level
+// keeps scalar loads.  r02 issued 144 4-byte loads per level (3 instructions of scattered dwords).
+constexpr int kCorrRows = 12, kCorrCols = 16;
+constexpr int kCorrLvl = kCorrRows * kCorrCols;
 
 __global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
-  __shared__ float win[4][4 * kCorrLvl];
+  __shared__ __attribute__((aligned(16))) float win[4][4 * kCorrLvl];
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const int64_t npix = k.total / 324;
   const int64_t pix = (int64_t)blockIdx.x * 4 + wave;  // n*h*w + y*w + x
@@ -348,26 +350,39 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
   const float fx = k.flow[pc * k.flow_ldc + 0];
   const float fy = k.flow[pc * k.flow_ldc + 1];
   float* mywin = win[wave];
-  int ox[4], oy[4];
+  int ox[4], oy[4];  // window origin: row of the first window row, 4-aligned column at or below the first window column
 #pragma unroll
   for (int lvl = 0; lvl < 4; ++lvl) {
     const float scale = 1.f / (float)(1 << lvl);
     float bx = ((float)px + fx) * scale, by = ((float)py + fy) * scale;
     if (!(fabsf(bx) < 1.0e6f)) bx = -1.0e6f;  // NaN / Inf / absurd flow: a window far outside the plane (all zeros)
     if (!(fabsf(by) < 1.0e6f)) by = -1.0e6f;
-    ox[lvl] = (int)floorf(bx) - 5;
+    ox[lvl] = ((int)floorf(bx) - 5) & ~3;
     oy[lvl] = (int)floorf(by) - 5;
     const int H = k.ph[lvl], W = k.pw[lvl];
     const int tl = k.tiled[lvl];
-    const float* plane = k.pyr[lvl] + pc * plane_pitch(H, W, tl);
+    const int64_t pitch = plane_pitch(H, W, tl);
+    const float* plane = k.pyr[lvl] + pc * pitch;
+    float* lw = mywin + lvl * kCorrLvl;
+    if (tl || ((W & 3) == 0 && (pitch & 3) == 0)) {
+      // 16-byte pieces; a tiled plane is valid (zero) up to its padded size
+      const int Hv = tl ? ((H + 3) & ~3) : H, Wv = tl ? ((W + 7) & ~7) : W;
+      if (lane < kCorrRows * 4) {
+        const int r = lane >> 2, q = lane & 3;
+        const int y = oy[lvl] + r, x0 = ox[lvl] + 4 * q;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (active && (unsigned)y < (unsigned)Hv && (unsigned)x0 < (unsigned)Wv)
+          v = *reinterpret_cast<const f4*>(plane + plane_off(y, x0, W, tl));
+        *reinterpret_cast<f4*>(lw + r * kCorrCols + 4 * q) = v;
+      }
+    } else {
 #pragma unroll
-    for (int it = 0; it < (kCorrLvl + 63) / 64; ++it) {
-      const int idx = lane + it * 64;
-      if (idx < kCorrLvl) {
-        const int r = idx / kCorrWin, c = idx - r * kCorrWin;
+      for (int it = 0; it < kCorrLvl / 64; ++it) {
+        const int idx = lane + it * 64;
+        const int r = idx / kCorrCols, c = idx - r * kCorrCols;
         const int y = oy[lvl] + r, x = ox[lvl] + c;
         const bool in = active && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        mywin[lvl * kCorrLvl + idx] = in ? plane[plane_off(y, x, W, tl)] : 0.f;
+        lw[idx] = in ? plane[(int64_t)y * W + x] : 0.f;
       }
     }
   }
@@ -394,7 +409,8 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
     const float iy = ((yn + 1.f) / 2.f) * (float)(H - 1);
     const float flx = floorf(ix), fly = floorf(iy);
     const float ax = ix - flx, ay = iy - fly;
-    // window-local corner (0 <= l <= 10 for every in-range coordinate; anything else lies outside the plane)
+    // window-local corner (every in-range coordinate falls inside the staged 12 x 16 window; anything else lies outside
+    // the plane)
     int lx = (int)flx, ly = (int)fly;
     int olx = 0, oly = 0;
 #pragma unroll
@@ -406,13 +422,13 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(const LookupK k) {
     lx -= olx;
     ly -= oly;
     float v = 0.f;
-    if ((unsigned)lx < (unsigned)(kCorrWin - 1) && (unsigned)ly < (unsigned)(kCorrWin - 1)) {
-      const float* w0 = mywin + lvl * kCorrLvl + ly * kCorrWin + lx;
+    if ((unsigned)lx < (unsigned)(kCorrCols - 1) && (unsigned)ly < (unsigned)(kCorrRows - 1)) {
+      const float* w0 = mywin + lvl * kCorrLvl + ly * kCorrCols + lx;
       // out-of-plane corners are staged as 0: the sum below equals the reference's corner-by-corner accumulation
       v += w0[0] * (1.f - ax) * (1.f - ay);
       v += w0[1] * ax * (1.f - ay);
-      v += w0[kCorrWin] * (1.f - ax) * ay;
-      v += w0[kCorrWin + 1] * ax * ay;
+      v += w0[kCorrCols] * (1.f - ax) * ay;
+      v += w0[kCorrCols + 1] * ax * ay;
     }
     k.out[pix * k.out_ldc + ch] = v;
   }
