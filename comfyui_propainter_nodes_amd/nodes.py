@@ -71,11 +71,13 @@ class _Timer:
         self.marks = [("start", time.perf_counter())]
 
     collect = False
+    sync = True          # False: host time stamps only (where does the launching thread spend its time?)
     last: dict = {}
 
     def mark(self, name: str) -> None:
         if self.on:
-            torch.cuda.synchronize(self.device)
+            if _Timer.sync:
+                torch.cuda.synchronize(self.device)
             self.marks.append((name, time.perf_counter()))
 
     def done(self) -> None:
