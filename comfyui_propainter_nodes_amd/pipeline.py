@@ -253,41 +253,11 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     if trace is not None:
         trace.update(gt_flows=gt, pred_flows=pred, updated_frames=updated, updated_masks=upd, pred_imgs=[])
     schedule, spans, table = device_schedule(config)
+    props = gen.propagate_windows(st, [nb for nb, _ in schedule])
+    mark("feature_propagation(all windows batched)")
     finals = final_ranges(schedule, T) if sink is not None else None
-    # Feature propagation of window group g+1 (a chain of small dependent launches that fills a fraction of the chip) runs
-    # on a SIDE stream under the transformer / decoder of the windows of group g (large kernels) -- r03, SURVEY.md 8 f3.
-    # Group 0 is small so that the first windows start early; kernel selection does not depend on the batch,
-    # so the grouping changes no result bit.  Serial (one batch, one stream) with a trace, on the CPU emulator, PP_OVERLAP=0.
-    overlap = trace is None and dev.type == "cuda" and os.environ.get("PP_OVERLAP", "1") != "0" and len(schedule) > 4
-    nwin = len(schedule)
-    bounds = [0, nwin] if not overlap else sorted({0, min(2, nwin), *range(2 + (nwin - 2 + 3) // 4, nwin, max(1, (nwin - 2 + 3) // 4)), nwin})
-    groups = [list(range(a, b)) for a, b in zip(bounds, bounds[1:])]
-    props: dict = {}
-    ready: dict = {}
-    main = torch.cuda.current_stream(dev) if overlap else None
-    side = torch.cuda.Stream(dev) if overlap else None
-    if overlap:
-        state_ready = torch.cuda.Event()
-        state_ready.record(main)
-    for gi, grp in enumerate(groups):
-        if overlap and gi > 0:
-            with torch.cuda.stream(side):
-                if gi == 1:
-                    side.wait_event(state_ready)
-                outs = gen.propagate_windows(st, [schedule[wi][0] for wi in grp])
-                ev = torch.cuda.Event()
-                ev.record(side)
-            for o in outs:
-                o.record_stream(main)
-        else:
-            outs, ev = gen.propagate_windows(st, [schedule[wi][0] for wi in grp]), None
-        for wi, o in zip(grp, outs):
-            props[wi], ready[wi] = o, ev
-    mark("feature_propagation(first group; the rest on the side stream)" if overlap else "feature_propagation(all windows batched)")
     for wi, (nb, refs) in enumerate(schedule):
-        if ready[wi] is not None:
-            main.wait_event(ready[wi])
-        out = gen.forward_window(st, nb, refs, local_prop=props.pop(wi))
+        out = gen.forward_window(st, nb, refs, local_prop=props[wi])
         a, b = spans[wi]
         ops.compose_u8(out, table[0, a:b], table[1, a:b], md, fr_u8, comp)
         if trace is not None:
