@@ -582,9 +582,11 @@ __global__ void __launch_bounds__(256, 2) window_attention_f16_kernel(const Attn
       rk = fetch_rows(i + 5);
       if (decltype(P)::value == 0 && (i & 7) == 0) resolve_group((i >> 3) + 1);  // first read in step i + 3
       PP_TR(i, 3);
+      // S^T of the next tile is issued in the block of the row maxima (its 8 MFMAs run under the max chain), the
+      // exponentials then overlap the O^T MFMAs
+      const f16v s_next = qk(kf);
       softmax_head(s_cur, NoTail{}, kAtTile);
       PP_TR(i, 4);
-      const f16v s_next = qk(kf);
       exp_pv(s_cur, P);
       s_cur = s_next;
       PP_TR(i, 5);

@@ -161,3 +161,80 @@ def test_static_mask_window_flags_are_one_constant_of_the_clip(backend):
     moving = static.clone()
     moving[4:] = 0
     assert not torch.equal(ops.window_flags(moving, 4, 3, (5, 9)).cpu(), const)
+
+
+def _attention_reference(qkv, pkv, flags, t_ind, fh, fw):
+    """Brute-force torch fp32 restatement of the key sets of sparse_transformer.py:218-385 on given q|k|v tensors
+    (qkv [t,Hp,Wp,1536], pkv [t,npool,1024] as the kernel sees them): masked window = all queries of the window against, per
+    key frame, the window's 45 tokens + the 148 rolled neighbours + all pooled tokens; unmasked = per frame 45 x 45."""
+    t, Hp, Wp, _ = qkv.shape
+    out = torch.zeros(t, fh, fw, 512)
+    q_all, k_all, v_all = qkv[..., :512].float(), qkv[..., 512:1024].float(), qkv[..., 1024:].float()
+    rows = [r - 3 for r in range(5)] + [r + 3 for r in range(5)]
+    cols = [c - 5 for c in range(9)] + [c + 5 for c in range(9)]
+    nww = Wp // 9
+    for win in range((Hp // 5) * nww):
+        wi, wj = win // nww, win % nww
+        ys, xs = slice(5 * wi, 5 * wi + 5), slice(9 * wj, 9 * wj + 9)
+        for head in range(4):
+            hs = slice(128 * head, 128 * head + 128)
+            if int(flags[win]):
+                q = q_all[:, ys, xs, hs].reshape(-1, 128)
+                ks, vs = [], []
+                for fr in t_ind.tolist():
+                    ks.append(k_all[fr, ys, xs, hs].reshape(-1, 128)); vs.append(v_all[fr, ys, xs, hs].reshape(-1, 128))
+                    for dr in rows:
+                        for dc in cols:
+                            if 0 <= dr < 5 and 0 <= dc < 9:
+                                continue
+                            y, x = (5 * wi + dr) % Hp, (9 * wj + dc) % Wp
+                            ks.append(k_all[fr, y, x, hs][None]); vs.append(v_all[fr, y, x, hs][None])
+                    ks.append(pkv[fr, :, hs].float()); vs.append(pkv[fr, :, 512 + 128 * head:512 + 128 * head + 128].float())
+                K, V = torch.cat(ks), torch.cat(vs)
+                o = (torch.softmax(q @ K.t() / math.sqrt(128), -1) @ V).view(t, 5, 9, 128)
+            else:
+                q = q_all[:, ys, xs, hs].reshape(t, 45, 128)
+                K = k_all[:, ys, xs, hs].reshape(t, 45, 128)
+                V = v_all[:, ys, xs, hs].reshape(t, 45, 128)
+                o = (torch.softmax(q @ K.transpose(1, 2) / math.sqrt(128), -1) @ V).view(t, 5, 9, 128)
+            y1, x1 = min(5 * wi + 5, fh), min(9 * wj + 9, fw)
+            out[:, 5 * wi:y1, 9 * wj:x1, hs] = o[:, :y1 - 5 * wi, :x1 - 9 * wj]
+    return out
+
+
+def test_window_attention_deferred_rescale_is_exact_on_score_spikes(backend):
+    """The f16 kernel rescales O / l only when a row maximum of a wave grows by more than 2^8 in the exponent (deferred
+    rescale, csrc/window_attention.hip).  Random data almost never takes that branch after the first tile, so this test
+    forces it: single keys in LATE tiles (spatial, rolled-neighbour and pooled ones, in both key frames) are aligned with
+    single queries so that their raw scores exceed everything before them by far more than the threshold, other rows of the
+    same wave stay ordinary, and some spikes stay just BELOW the threshold (probabilities up to 2^8 against the old
+    reference).  Compared with a brute-force fp32 softmax over the same q|k|v."""
+    dev = backend
+    g = torch.Generator().manual_seed(41)
+    t, fh, fw = 4, 10, 18                          # 2 x 2 windows; npool = 2 * 4 = 8; nk = 2 * (193 + 8) = 402: 13 tiles
+    qkv = (torch.randn(t, fh, fw, 1536, generator=g) * 0.6).half()
+    pkv = (torch.randn(t, 8, 1024, generator=g) * 0.6).half()
+    flags = torch.tensor([1, 0, 1, 1], dtype=torch.int32)
+    t_ind = torch.arange(1, t, 2, dtype=torch.int32)
+
+    def spike(kvec_setter, q_pos, head, gain):
+        tq, yq, xq = q_pos
+        q = qkv[tq, yq, xq, 128 * head:128 * head + 128].float()
+        kvec_setter((gain * q / q.norm()).half())
+
+    # window 0 (rows 0..4, cols 0..8), head 0: a huge spike on a rolled-neighbour key of key frame 3 (late tiles)
+    spike(lambda v: qkv[3, 6, 10].__setitem__(slice(512, 640), v), (2, 1, 3), 0, 60.0)
+    # ... a pooled key of key frame 1 for another query of the same wave, just below the threshold (2^8 ~ raw score gap 63)
+    spike(lambda v: pkv[1, 5].__setitem__(slice(0, 128), v), (2, 2, 4), 0, 9.0)
+    # window 2 (rows 5..9, cols 0..8), head 3: a spike on one of the window's own tokens in key frame 3
+    spike(lambda v: qkv[3, 7, 2].__setitem__(slice(512 + 384, 512 + 512), v), (0, 9, 8), 3, 45.0)
+    # window 3, head 1: two spikes for the same query in different tiles, the later one larger (two rescales)
+    spike(lambda v: qkv[1, 9, 17].__setitem__(slice(512 + 128, 512 + 256), v), (3, 6, 12), 1, 30.0)
+    spike(lambda v: pkv[3, 7].__setitem__(slice(128, 256), v), (3, 6, 12), 1, 70.0)
+    ref = _attention_reference(qkv, pkv, flags, t_ind, fh, fw)
+    out = torch.empty(t, fh, fw, 512, dtype=torch.float16, device=dev)
+    ops.window_attention(qkv.to(dev), pkv.to(dev), flags.to(dev), t_ind.to(dev), out)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+    # the spiked queries put (almost) all their weight on the spiked key: the output row is that key's value row
+    assert (out[2, 1, 3, :128].float().cpu() - qkv[3, 6, 10, 1024:1152].float()).abs().max().item() < 2e-2
