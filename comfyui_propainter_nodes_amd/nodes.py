@@ -276,7 +276,13 @@ def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer, static_masks=False):
 
 
 class ProPainterInpaint:
-    """ComfyUI Node for performing inpainting on video frames using ProPainter."""
+    """ComfyUI Node for performing inpainting on video frames using ProPainter.
+
+    `fp16`: "enable" = f16 storage of flow completion and the generator (the reference's `.half()`), RAFT on f32 tensors;
+    "disable" = fp32 STORAGE of all three networks.  In both modes the matrix products run on the f16 matrix pipe: fp32
+    tensors multiply as two-term f16 splits (PP_F32X2: 22 significant bits per operand, fp32 accumulation; PP_F32_GEMM=exact
+    selects the f32 MFMA instructions) and the attention core rounds q, k, v and the probabilities to f16 -- "disable" is
+    72-78 dB from the reference's fp32 CPU run, not bit-level fp32 arithmetic."""
 
     def __init__(self):
         pass

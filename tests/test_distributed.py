@@ -201,6 +201,16 @@ def test_two_ranks_over_rccl_match_single_process(hip_lib, tmp_path):
 
 
 @pytest.mark.gpu
+def test_one_rank_rccl_group_runs_the_sharded_driver(hip_lib, tmp_path):
+    """The RCCL code path on the ONE GPU of the test box: a 1-rank "nccl" process group (communicator creation with
+    device_id, device tensors on the wire, all_gather / barrier through RCCL; no peer so no point-to-point traffic) driving
+    the sharded runner -- the branch `bench.py --gpus N` takes, executed before the driver times it on N GPUs."""
+    port = 29500 + (os.getpid() * 7 + 23) % 2000
+    mp.spawn(_gpu_worker, args=(1, port, str(tmp_path), "nccl"), nprocs=1, join=True)
+    assert torch.equal(torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "single.pt"))
+
+
+@pytest.mark.gpu
 def test_bench_spawns_its_own_ranks(hip_lib):
     """`python bench.py --gpus 2` run bare launches two ranks under torch.distributed.run (gloo here: one GPU on the
     test box; the driver's SCALE run uses RCCL, one rank per GPU) and prints one JSON line with n_gpus = 2."""
