@@ -56,3 +56,31 @@ def test_bad_arguments_return_error_codes(emu_lib):
     rc = emu_lib.cdll.pp_conv2d(ctypes.c_void_p(0), ctypes.byref(P))
     assert rc == lib.CONSTS["PP_ERR_BAD_ARG"]
     assert b"nseg" in emu_lib.cdll.pp_last_error()
+
+
+def test_knobs_are_cached_until_reload(emu_lib, capfd, monkeypatch):
+    """csrc/pp_options.h: the PP_CONV_* knobs are read from the environment once; a change is seen only after
+    pp_reload_options() (lib.reload_options(), what the `pp_knobs` fixture of the tests calls)."""
+    import torch
+
+    from comfyui_propainter_nodes_amd import lib, ops
+
+    def run():
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(1, 12, 20, 32, generator=g)
+        spec = ops.make_conv_spec(torch.randn(64, 32, 3, 3, generator=g) * 0.1, None, torch.float32, padding=1, split=True)
+        out = torch.empty(1, 12, 20, 64)
+        ops.conv2d(spec, [x], out)
+        return capfd.readouterr().err
+
+    monkeypatch.setenv("PP_CONV_HALO", "force")
+    lib.reload_options()
+    assert "halo-tile kernel" not in run()               # PP_CONV_TRACE is not set: nothing is printed
+    monkeypatch.setenv("PP_CONV_TRACE", "1")
+    assert "halo-tile kernel" not in run()               # ... and setting it is not seen: the knobs are cached
+    lib.reload_options()
+    assert "halo-tile kernel" in run()                   # ... until the library is told to read them again
+    monkeypatch.delenv("PP_CONV_TRACE")
+    monkeypatch.delenv("PP_CONV_HALO")
+    lib.reload_options()
+    assert "halo-tile kernel" not in run()
