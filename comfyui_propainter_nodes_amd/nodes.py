@@ -121,37 +121,6 @@ def _pinned_release(buf: torch.Tensor) -> None:
         _STAGE[tuple(buf.shape)] = buf
 
 
-def _upload_and_encode(image: torch.Tensor, device, raft, canvas_hw=None, offset=(0, 0)):
-    """The node's IMAGE (host fp32, pageable) -> (uint8 frames, fp32 [-1,1] frames, RAFT encodings) on the device, in chunks
-    of RAFT's encoder batch: chunk k+1 crosses PCIe on a copy stream (the pageable copy blocks this thread, not the GPU) while
-    fnet / cnet of chunk k run -- the 5 ms H2D of an 80-frame 640x360 clip disappears under the ~40 ms of encoder work
-    (results identical: the encoders are per-frame functions)."""
-    T, H, W, _ = image.shape
-    ho, wo = canvas_hw or (H, W)
-    src = image.detach()
-    if not src.is_contiguous():
-        src = src.contiguous()
-    fr_u8 = torch.empty(T, ho, wo, 3, dtype=torch.uint8, device=device)
-    fr_f32 = torch.empty(T, ho, wo, 3, dtype=torch.float32, device=device)
-    encodable = ho % 8 == 0 and wo % 8 == 0 and ho >= 128 and wo >= 128
-    fmap, ctx = raft.alloc_encoding(T, ho, wo, device) if encodable else (None, None)
-    main = torch.cuda.current_stream(device)
-    copy = torch.cuda.Stream(device)
-    step = raft.enc_chunk
-    for s in range(0, T, step):
-        e = min(T, s + step)
-        with torch.cuda.stream(copy):
-            chunk = src[s:e].to(device, non_blocking=True)
-            arrived = torch.cuda.Event()
-            arrived.record(copy)
-        main.wait_event(arrived)
-        chunk.record_stream(main)
-        ops.frames_from_image(chunk, canvas_hw, offset, out=(fr_u8[s:e], fr_f32[s:e]))
-        if encodable:
-            raft.encode_chunk(fr_f32[s:e], fmap[s:e], ctx[s:e])
-    return fr_u8, fr_f32, ((fmap, ctx) if encodable else None)
-
-
 def _expand_masks(m: torch.Tensor, T: int) -> torch.Tensor:
     return m.expand(T, -1, -1).contiguous() if m.shape[0] == 1 and T != 1 else m
 
@@ -281,7 +250,7 @@ class _HostImageSink:
 TRACE: dict | None = None  # debugging / test aid: when a dict, the next node call leaves its stage tensors in it
 
 
-def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer, static_masks=False, raft_encoded=None):
+def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer, static_masks=False):
     if TRACE is not None:
         TRACE.update(frames_u8=fr_u8, flow_masks=fm, masks_dilated=md)
     # (r03: measured on the MI355X box, node call of the 80-frame clip: PP_OUTPUT=device 452 ms, host 466 ms, stream 496 ms --
@@ -291,7 +260,7 @@ def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer, static_masks=False, 
     sink = _HostImageSink(*fr_u8.shape[:3], fr_u8.device) if stream_out else None
     try:
         comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32, sink=sink,
-                              static_masks=static_masks, raft_encoded=raft_encoded)
+                              static_masks=static_masks)
     except BaseException:
         if sink is not None:
             sink.abandon()             # release the worker thread: a failed call must not leave it parked on the queue
@@ -348,23 +317,18 @@ class ProPainterInpaint:
                                   image_config.process_size)
         models = initialize_models(device, config.fp16)
         if _device_io_ok(image, image_config.process_size, input_size, mask):
-            # the fp32 IMAGE is uploaded in chunks under RAFT's encoders (uint8 conversion and [-1,1] scaling on the device),
-            # MASK in one small H2D; mask dilation on the device
+            # one H2D of the fp32 IMAGE / MASK; uint8 conversion, [-1,1] scaling and mask dilation on the device
+            fr_u8, fr_f32 = ops.frames_from_image(image.detach().to(device).contiguous())
             m = mask.detach().to(device).contiguous()
-            if torch.device(device).type == "cuda":
-                fr_u8, fr_f32, enc = _upload_and_encode(image, device, models.raft_model)
-            else:   # (the x86 emulator of the tests: no streams)
-                fr_u8, fr_f32 = ops.frames_from_image(image.detach().to(device).contiguous())
-                enc = None
             fm = _expand_masks(ops.mask_dilate(m, flow_mask_dilates), video_length)
             md = _expand_masks(ops.mask_dilate(m, mask_dilates), video_length)
         else:
             frames_u8, flow_masks, masks_dilated = prepare_frames_and_masks(image_to_uint8_frames(image), mask, image_config)
-            fr_u8, fr_f32, enc = torch.from_numpy(frames_u8).to(device), None, None
+            fr_u8, fr_f32 = torch.from_numpy(frames_u8).to(device), None
             fm, md = torch.from_numpy(flow_masks).to(device), torch.from_numpy(masks_dilated).to(device)
         tm.mark("input(H2D, u8, masks)")
         print(f"\nProcessing  {config.video_length} frames...")
-        return _run(models, config, fr_u8, fr_f32, fm, md, tm, static_masks=mask.shape[0] == 1, raft_encoded=enc)
+        return _run(models, config, fr_u8, fr_f32, fm, md, tm, static_masks=mask.shape[0] == 1)
 
 
 class ProPainterOutpaint:

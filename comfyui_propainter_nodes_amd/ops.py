@@ -787,24 +787,16 @@ def compose_u8(pred: torch.Tensor, frame_ids: torch.Tensor, first: torch.Tensor,
 # device-side pre / post-processing (the node's byte plumbing)
 # --------------------------------------------------------------------------------------------
 def frames_from_image(image: torch.Tensor, canvas_hw: tuple[int, int] | None = None, offset: tuple[int, int] = (0, 0),
-                      want_f32: bool = True, out: tuple[torch.Tensor, torch.Tensor] | None = None):
+                      want_f32: bool = True):
     """IMAGE fp32 [T,H,W,3] on the device -> (uint8 frames [T,Ho,Wo,3], fp32 frames in [-1,1] or None); with a
-    canvas the frames are placed at `offset` = (oy, ox) inside zeros (the outpaint canvas).  `out` = preallocated
-    (uint8, fp32) destinations, e.g. slices of the clip's tensors when the IMAGE arrives in chunks."""
+    canvas the frames are placed at `offset` = (oy, ox) inside zeros (the outpaint canvas)."""
     check_device(image)
     if image.dtype != torch.float32 or image.dim() != 4 or image.shape[3] != 3 or not image.is_contiguous():
         raise ValueError("frames_from_image: expected a dense fp32 [T,H,W,3] image")
     t, h, w, _ = image.shape
     ho, wo = canvas_hw or (h, w)
-    if out is not None:
-        u8, f32 = out
-        check_device(u8, f32)
-        if (tuple(u8.shape) != (t, ho, wo, 3) or tuple(f32.shape) != (t, ho, wo, 3) or u8.dtype != torch.uint8
-                or f32.dtype != torch.float32 or not u8.is_contiguous() or not f32.is_contiguous()):
-            raise ValueError("frames_from_image: bad preallocated outputs")
-    else:
-        u8 = torch.empty(t, ho, wo, 3, dtype=torch.uint8, device=image.device)
-        f32 = torch.empty(t, ho, wo, 3, dtype=torch.float32, device=image.device) if want_f32 else None
+    u8 = torch.empty(t, ho, wo, 3, dtype=torch.uint8, device=image.device)
+    f32 = torch.empty(t, ho, wo, 3, dtype=torch.float32, device=image.device) if want_f32 else None
     P = _lib.STRUCTS["pp_frames_from_image_params"]()
     P.image, P.out_u8 = image.data_ptr(), u8.data_ptr()
     if f32 is not None:

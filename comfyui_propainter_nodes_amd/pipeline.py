@@ -141,9 +141,9 @@ def models_from_state_dicts(sds: dict, device, fp16: str = "enable", provenance:
                   InpaintGeneratorMI355(sds["gen"], device, dt), provenance)
 
 
-def compute_flow(raft_model: RaftFlow, frames: torch.Tensor, config: ProPainterConfig, encoded=None) -> torch.Tensor:
+def compute_flow(raft_model: RaftFlow, frames: torch.Tensor, config: ProPainterConfig) -> torch.Tensor:
     """frames fp32 [T,H,W,3] -> gt flows fp32 [2,T-1,H,W,2] (forward, backward)."""
-    ff, fb = raft_model(frames, config.raft_iter, encoded=encoded)
+    ff, fb = raft_model(frames, config.raft_iter)
     return torch.stack([ff, fb], 0)
 
 
@@ -209,7 +209,7 @@ def device_schedule(config: ProPainterConfig):
 
 def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, config: ProPainterConfig,
                    trace: dict | None = None, to_host: bool = True, frames_f32: torch.Tensor | None = None,
-                   sink=None, static_masks=False, raft_encoded=None) -> torch.Tensor:
+                   sink=None, static_masks=False) -> torch.Tensor:
     """uint8 arrays / tensors in ([T,H,W,3], [T,H,W], [T,H,W]) -> composed uint8 frames [T,H,W,3]
     (CPU tensor, or left in HBM when `to_host` is False).  `frames_f32` = the fp32 [-1,1] frames when the caller
     already produced them on the device (ops.frames_from_image).
@@ -217,7 +217,6 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     `sink` (optional): an object with `frames_final(comp, lo, hi)`, called as soon as frames [lo, hi) of the composed clip
     can no longer change (no later window has them as local frames) -- the node streams them to the host under the
     remaining windows (nodes._HostImageSink).
-    `raft_encoded` = RAFT's (fmap, ctx) of `frames_f32` when the caller encoded the frames as they arrived (nodes.py).
     `static_masks`: True when every frame has the same masks (one MASK frame, outpaint borders), or a hashable key of the
     outpaint geometry: the masked-window set of the transformer is then computed once per clip / once per geometry.
 
@@ -238,7 +237,7 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     md = torch.as_tensor(masks_dilated_u8).to(dev).contiguous()
     T, H, W, _ = fr_u8.shape
     frames = frames_f32 if frames_f32 is not None else ops.frames_from_u8(fr_u8)  # to_tensors(): x/255*2-1 (image_utils.py:191)
-    gt = compute_flow(models.raft_model, frames, config, encoded=raft_encoded if frames_f32 is not None else None)
+    gt = compute_flow(models.raft_model, frames, config)
     mark("raft")
     pred = complete_flow(models.flow_model, gt, fm, config.subvideo_length)
     mark("flow_completion")

@@ -168,21 +168,13 @@ class RaftFlow:
         """frames [T,H,W,3] fp32 in [-1,1] -> (fmap [T,h8,w8,256], ctx [T,h8,w8,256] = tanh|relu)."""
         T, H, W, _ = frames.shape
         h8, w8 = H // 8, W // 8
-        fmap, ctx = self.alloc_encoding(T, H, W, frames.device)
+        fmap = torch.empty(T, h8, w8, 256, device=frames.device)
+        ctx = torch.empty(T, h8, w8, 256, device=frames.device)
         for s in range(0, T, self.enc_chunk):
             e = min(T, s + self.enc_chunk)
-            self.encode_chunk(frames[s:e], fmap[s:e], ctx[s:e])
+            self.fnet(frames[s:e], fmap[s:e], split_tanh_relu=False)
+            self.cnet(frames[s:e], ctx[s:e], split_tanh_relu=True)
         return fmap, ctx
-
-    def alloc_encoding(self, T: int, H: int, W: int, device) -> tuple[torch.Tensor, torch.Tensor]:
-        return (torch.empty(T, H // 8, W // 8, 256, device=device), torch.empty(T, H // 8, W // 8, 256, device=device))
-
-    def encode_chunk(self, frames: torch.Tensor, fmap: torch.Tensor, ctx: torch.Tensor) -> None:
-        """fnet / cnet of at most `enc_chunk` frames into slices of the clip's encodings.  Both are per-frame functions
-        (instance norm per sample, eval-mode batch norm), so a clip may be encoded chunk by chunk as its frames arrive
-        (nodes.py uploads the IMAGE in chunks and encodes chunk k while chunk k+1 crosses PCIe)."""
-        self.fnet(frames, fmap, split_tanh_relu=False)
-        self.cnet(frames, ctx, split_tanh_relu=True)
 
     def _update_pairs(self, f1, f2, ctx, iters: int, flow_up: torch.Tensor, trace: dict | None = None) -> None:
         """One batch of pair-directions: f1,f2 [P,hw,256], ctx [P,h,w,256] -> flow_up [P,8h,8w,2]."""
@@ -252,16 +244,12 @@ class RaftFlow:
         if trace is not None:
             trace.update(flow_lr=flow.clone(), net=hcur.clone(), mask=mask)
 
-    def __call__(self, frames: torch.Tensor, iters: int, trace: dict | None = None,
-                 encoded: tuple[torch.Tensor, torch.Tensor] | None = None) -> tuple[torch.Tensor, torch.Tensor]:
-        """frames [T,H,W,3] fp32 in [-1,1] (channels-last) -> (flows_fwd, flows_bwd), each [T-1,H,W,2].
-        `encoded` = (fmap, ctx) of exactly these frames when the caller already ran encode_chunk() on them."""
+    def __call__(self, frames: torch.Tensor, iters: int, trace: dict | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """frames [T,H,W,3] fp32 in [-1,1] (channels-last) -> (flows_fwd, flows_bwd), each [T-1,H,W,2]."""
         T, H, W, _ = frames.shape
         if H % 8 or W % 8 or H < 128 or W < 128:
             raise ValueError("RAFT needs H, W multiples of 8 and >= 128 (reference limit, SURVEY.md 9.15)")
-        fmap, ctx = encoded if encoded is not None else self.encode(frames)
-        if tuple(fmap.shape) != (T, H // 8, W // 8, 256) or tuple(ctx.shape) != (T, H // 8, W // 8, 256):
-            raise ValueError("RAFT: the precomputed encodings do not belong to these frames")
+        fmap, ctx = self.encode(frames)
         if trace is not None:
             trace.update(fmap=fmap, ctx=ctx)
         h, w = H // 8, W // 8
