@@ -42,7 +42,7 @@ image, mask = synth.synthetic_clip(C["T"], C["H"], C["W"], 1234)
 node = nodes.ProPainterInpaint()
 args = (image, mask, C["W"], C["H"], C["mask_dilates"], C["flow_mask_dilates"], C["ref_stride"], C["neighbor_length"],
         C["subvideo_length"], C["raft_iter"], "enable")
-for mode in ("device", "host"):
+for mode in os.environ.get("NODE_GAP_MODES", "device,host").split(","):
     os.environ["PP_OUTPUT"] = mode.split("-")[0]
     nodes._HostImageSink.wait_mode = "sync" if mode.endswith("sync") else "poll"
     nodes._Timer.collect = False
