@@ -238,3 +238,26 @@ def test_window_attention_deferred_rescale_is_exact_on_score_spikes(backend):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
     # the spiked queries put (almost) all their weight on the spiked key: the output row is that key's value row
     assert (out[2, 1, 3, :128].float().cpu() - qkv[3, 6, 10, 1024:1152].float()).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("fh,fw,tiles", [(20, 18, 14), (20, 36, 15)])
+def test_window_attention_every_remainder_of_the_tile_loop(backend, fh, fw, tiles):
+    """The f16 kernel walks the keys four 32-key steps per loop trip (static ring slots) and finishes with 0..3 remainder
+    steps plus a masked last tile at ring position (tiles - 1) % 4.  The other attention cases all have tiles % 4 == 1 or 0;
+    these two grids give 14 and 15 tiles (remainders 1 and 2) -- against the brute-force fp32 softmax over the same q|k|v."""
+    dev = backend
+    g = torch.Generator().manual_seed(43)
+    t = 4
+    npool = (fh // 4) * (fw // 4)
+    assert -(-(2 * (193 + npool)) // 32) == tiles
+    qkv = (torch.randn(t, fh, fw, 1536, generator=g) * 0.7).half()
+    pkv = (torch.randn(t, npool, 1024, generator=g) * 0.7).half()
+    nwin = (fh // 5) * (fw // 9)
+    flags = torch.zeros(nwin, dtype=torch.int32)
+    flags[1] = flags[nwin - 2] = 1
+    t_ind = torch.arange(0, t, 2, dtype=torch.int32)
+    ref = _attention_reference(qkv, pkv, flags, t_ind, fh, fw)
+    out = torch.empty(t, fh, fw, 512, dtype=torch.float16, device=dev)
+    ops.window_attention(qkv.to(dev), pkv.to(dev), flags.to(dev), t_ind.to(dev), out)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
