@@ -340,15 +340,8 @@ __device__ __forceinline__ void split_pair(float c0, float c1, h2& hh, h2& ll) {
   ll = cvt_pkrtz_f16(t0 * 2048.f, t1 * 2048.f);
 }
 
-// one 16-byte f16 MFMA fragment from LDS (PP_ABLATE & 16: a register constant instead)
-__device__ __forceinline__ h8 lds_frag(const void* ptr) {
-#if PP_ABLATE & 16
-  const half_t v = (half_t)(float)(reinterpret_cast<uintptr_t>(ptr) & 1);
-  return h8{v, v, v, v, v, v, v, v};
-#else
-  return *reinterpret_cast<const h8*>(ptr);
-#endif
-}
+// one 16-byte f16 MFMA fragment from LDS
+__device__ __forceinline__ h8 lds_frag(const void* ptr) { return *reinterpret_cast<const h8*>(ptr); }
 
 template <typename F>
 static int launch_by_cout(void* stream, const ConvK& k, int Z) {

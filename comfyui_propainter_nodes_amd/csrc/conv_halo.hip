@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_kernel(const 
     const int woff = w_tap * p.chunks_per_tap * 32 + w_sbase + w_rem * 32;
 #pragma unroll
     for (int i = 0; i < WPASS; ++i)
-      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
+      glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
     w_advance();
   };
 
@@ -137,12 +137,8 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_kernel(const 
     for (int i = 0; i < XPASS; ++i) {
       const bool ok0 = xpix[i] >= 0 && c0 < x_C, ok1 = xpix[i] >= 0 && c0 + 4 < x_C;
       const float* src = ok0 ? x_base + (int64_t)xpix[i] * x_ldc + c0 : x_base;
-      if constexpr (!(PP_ABLATE & 2)) {
-        gload16_hidden(xreg[i][0], src);
-        gload16_hidden(xreg[i][1], src + (ok1 ? 4 : 0));
-      } else {
-        asm volatile("" : "=v"(xreg[i][0]), "=v"(xreg[i][1]) : "v"(src), "v"(ok1));
-      }
+      gload16_hidden(xreg[i][0], src);
+      gload16_hidden(xreg[i][1], src + (ok1 ? 4 : 0));
       okbits |= ((ok0 ? 1 : 0) | (ok1 ? 2 : 0)) << (2 * i);
     }
     xok = okbits;

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_halo_f16_kernel(const ConvK
     const int woff = w_tap * p.chunks_per_tap * 32 + w_sbase + w_rem * 32;
 #pragma unroll
     for (int i = 0; i < WPASS; ++i)
-      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
+      glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
     if (++w_tap == ntaps) {
       w_tap = 0;
       if (++w_rem == w_chunks) {
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_halo_f16_kernel(const ConvK
     for (int i = 0; i < XPASS; ++i) {
       const bool ok = xpix[i] >= 0 && c0 < x_C;
       const void* src = ok ? static_cast<const void*>(x_base + (int64_t)xpix[i] * x_ldc + c0) : static_cast<const void*>(pp_zero16);
-      if constexpr (!(PP_ABLATE & 2)) glds16(src, xt + (i * NT + wave * 64) * 16);
+      glds16(src, xt + (i * NT + wave * 64) * 16);
     }
     if (++x_rem == x_chunks) {
       x_rem = 0;

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(const ConvK p)
   // short to hide a global->LDS round trip with only one chunk ahead.
   constexpr int NST = G::NST;
   // global_load_lds instructions per thread per chunk (ablation builds count only what they issue)
-  constexpr int NLOADS = ((PP_ABLATE & 2) ? 0 : XPASS) + ((PP_ABLATE & 4) ? 0 : WPASS);
+  constexpr int NLOADS = XPASS + WPASS;
   typedef typename Frag<T>::piece piece_t;
 
   T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);  // [2 stages][KC][ X: BP rows | W: BC rows ][LDK]
@@ -245,12 +245,12 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(const ConvK p)
         pix = prow[i] + tapoff;
       }
       const void* src = ok ? static_cast<const void*>(sbase + pix * ldc + c0) : static_cast<const void*>(pp_zero16);
-      if constexpr (!(PP_ABLATE & 2)) glds16(src, xt + (i * NT + wave_x * 64) * EPP);
+      glds16(src, xt + (i * NT + wave_x * 64) * EPP);
     }
     const int woff = it_woff();
 #pragma unroll
     for (int i = 0; i < WPASS; ++i)
-      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * EPP);
+      glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * EPP);
     advance();
   };
   auto dma_stage = [&](int buf) PP_INLINE_LAMBDA { static_for<KC>([&](auto kci) { dma_chunk(buf, kci); }); };

@@ -30,9 +30,8 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
   // LDS: 2 pixel stages + 3 weight stages.  Pixels of chunk q+2 are in flight to registers and weights of chunk
   // q+2 in flight to LDS while chunk q is multiplied: two chunks of latency cover per work-group.
   constexpr int XSTAGE = BP * ROWB, WSTAGE = BCP * ROWB;
-  // vector-memory instructions per thread per chunk (an ablation build that drops loads must also stop counting them:
-  // a hidden load that lands after its too-lenient wait overwrites a register the compiler has already re-purposed)
-  constexpr int NLOADS = ((PP_ABLATE & 4) ? 0 : WPASS) + ((PP_ABLATE & 2) ? 0 : 2 * XPASS);
+  // vector-memory instructions per thread per chunk
+  constexpr int NLOADS = WPASS + 2 * XPASS;
   constexpr float LINV = 1.f / 2048.f;
 
   unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
@@ -131,7 +130,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
     const int woff = it_woff();
 #pragma unroll
     for (int i = 0; i < WPASS; ++i)
-      if constexpr (!(PP_ABLATE & 4)) glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
+      glds16(wrow[i] + woff, wt + (i * NT + wave * 64) * 16);
     const int c0 = it_rem * 32 + xj * 8;
     const int dy = it_ky * p.dh, dx = it_kx * p.dw;
     const int64_t tapoff = (int64_t)dy * p.W + dx;
@@ -153,12 +152,8 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
       // segment channel counts are multiples of 4: each half octet is either fully valid or padding
       const bool ok0 = ok && (c0 < it_C), ok1 = ok && (c0 + 4 < it_C);
       const float* src = ok0 ? cbase + pix * it_ldc : it_base;
-      if constexpr (!(PP_ABLATE & 2)) {
-        gload16_hidden(xreg[P][i][0], src);
-        gload16_hidden(xreg[P][i][1], src + (ok1 ? 4 : 0));
-      } else {
-        asm volatile("" : "=v"(xreg[P][i][0]), "=v"(xreg[P][i][1]) : "v"(src), "v"(ok1));
-      }
+      gload16_hidden(xreg[P][i][0], src);
+      gload16_hidden(xreg[P][i][1], src + (ok1 ? 4 : 0));
       okbits |= (ok0 ? 1 : 0) << (2 * i) | (ok1 ? 2 : 0) << (2 * i);
     }
     xok[P] = okbits;
@@ -182,20 +177,12 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
-        if constexpr (!(PP_ABLATE & 8)) {
-          h2 hh, ll;
-          split_pair(c0, c1, hh, ll);
-          h[e] = hh[0];
-          h[e + 1] = hh[1];
-          l[e] = ll[0];
-          l[e + 1] = ll[1];
-        } else {  // no arithmetic: the raw bit patterns
-          const h2 r0 = __builtin_bit_cast(h2, c0), r1 = __builtin_bit_cast(h2, c1);
-          h[e] = r0[0];
-          h[e + 1] = r0[1];
-          l[e] = r1[0];
-          l[e + 1] = r1[1];
-        }
+        h2 hh, ll;
+        split_pair(c0, c1, hh, ll);
+        h[e] = hh[0];
+        h[e + 1] = hh[1];
+        l[e] = ll[0];
+        l[e + 1] = ll[1];
       }
       unsigned char* rowp = xs + (xrow0 + i * XROWS) * ROWB;
       *reinterpret_cast<h8*>(rowp + xoff_h) = h;

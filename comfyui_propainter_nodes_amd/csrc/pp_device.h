@@ -39,21 +39,12 @@ constexpr int kWave = 64;
 //   16x16x4  f32 : lane l holds A[row = l&15][k = l>>4], B[k = l>>4][col = l&15];
 //   C/D (both)   : lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3.
 // ---------------------------------------------------------------------------------------
-// PP_ABLATE (profiling aid, tools/ablate_conv.py; 0 in every product build): a bit mask that removes ONE ingredient
-// of the convolution kernels so that its cost can be read off a timing difference (results are then meaningless):
-//   1 no MFMA (operands kept alive)   2 no pixel-tile global loads   4 no weight-tile global loads
-//   8 no operand split arithmetic    16 no LDS fragment reads       32 no work-group barriers in the K loop
-#ifndef PP_ABLATE
-#define PP_ABLATE 0
-#endif
+// (The PP_ABLATE profiling hooks of rounds 1-2 -- compile one ingredient of the convolution kernels out and read its cost off
+// the timing difference -- are no longer part of the product sources: tools/ablate_hooks.patch re-inserts them into a scratch
+// copy of csrc/ for tools/ablate_*.sh.)
 #ifndef PP_EMU
 __device__ __forceinline__ f4 mfma_16x16x32_f16(h8 a, h8 b, f4 c) {
-#if PP_ABLATE & 1
-  asm volatile("" ::"v"(a), "v"(b));
-  return c;
-#else
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-#endif
 }
 __device__ __forceinline__ f4 mfma_16x16x4_f32(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -98,9 +89,7 @@ __device__ __forceinline__ void wait_vmcnt_hidden() {
 // LDS writes / reads of this wave retired (what __syncthreads() would wait for besides vmcnt)
 __device__ __forceinline__ void pp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void pp_barrier() {
-#if !(PP_ABLATE & 32)
   __builtin_amdgcn_s_barrier();
-#endif
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }

@@ -3,8 +3,9 @@
     python tools/ablate_conv.py --build     # here (CPU): variant libraries tools/ablate/libpp_abl_<mask>.so
     python tools/ablate_conv.py             # on the MI355X (gpurun): time every variant, write gpurun_out/ablate.json
 
-Each variant is the product library with conv_igemm.hip / conv_split.hip compiled with -DPP_ABLATE=<mask> (pp_device.h: 1 no MFMA,
-2 no pixel loads, 4 no weight loads, 8 no operand-split arithmetic, 16 no LDS fragment reads, 32 no K-loop barriers).
+Each variant is the product library with conv_igemm.hip / conv_split.hip compiled with -DPP_ABLATE=<mask> (1 no MFMA, 2 no pixel
+loads, 4 no weight loads, 8 no operand-split arithmetic, 16 no LDS fragment reads, 32 no K-loop barriers) from a scratch copy of
+csrc/ that tools/ablate_src.sh patches with tools/ablate_hooks.patch: the product sources carry no ablation code.
 The results of an ablated kernel are meaningless; only the time differences are read."""
 import json
 import subprocess
@@ -22,6 +23,7 @@ def build():
     from comfyui_propainter_nodes_amd import build as B
 
     B.build_hip()
+    src = Path(subprocess.run([str(ROOT / "tools" / "ablate_src.sh")], check=True, capture_output=True, text=True).stdout.strip())
     conv = ("conv_igemm", "conv_split")
     objs = [o for o in (B.PKG / "build" / "hip").glob("*.o") if o.stem not in conv]
 
@@ -30,7 +32,7 @@ def build():
         for name in conv:
             obj = OUT / f"{name}_{mask}.o"
             subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-DPP_ABLATE={mask}",
-                            "-I", str(B.CSRC), "-I", str(ROOT / "include"), "-c", str(B.CSRC / f"{name}.hip"), "-o", str(obj)],
+                            "-I", str(src), "-I", str(ROOT / "include"), "-c", str(src / f"{name}.hip"), "-o", str(obj)],
                            check=True)
             mine.append(obj)
         so = OUT / f"libpp_abl_{mask}.so"

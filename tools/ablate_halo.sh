@@ -1,14 +1,16 @@
 #!/bin/bash
 # Ablation builds of the halo-tile kernels: whole library with conv_halo.hip / conv_halo_f16.hip compiled -DPP_ABLATE=<mask> (1 no MFMA, 2 no pixel
 # loads, 4 no weight copies, 16 no LDS fragment reads, 32 no barriers).  --build here (CPU); without arguments on the MI355X:
-# convbench against every variant (results of an ablated kernel are meaningless; only the time differences are read).
+# convbench against every variant.  The hooks are not in the product sources: the variants compile from the scratch copy that
+# tools/ablate_src.sh patches with tools/ablate_hooks.patch (results of an ablated kernel are meaningless; only the time differences are read).
 cd "$(dirname "$0")/.."
 PKG=comfyui_propainter_nodes_amd
 if [ "${1:-}" = "--build" ]; then
+  SRC=$(tools/ablate_src.sh) || exit 1
   for m in 1 2 4 6 16 32; do
     mkdir -p tools/ablate/$m
     for f in conv_halo conv_halo_f16; do
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPP_ABLATE=$m -I $PKG/csrc -I include -c $PKG/csrc/$f.hip -o tools/ablate/$m/$f.o &
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPP_ABLATE=$m -I $SRC -I include -c $SRC/$f.hip -o tools/ablate/$m/$f.o &
     done
   done; wait
   for m in 1 2 4 6 16 32; do

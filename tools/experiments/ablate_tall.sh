@@ -1,4 +1,5 @@
 #!/bin/bash
+# ARCHIVED with conv_halo_tall.hip (not built any more; needs the hooks of tools/ablate_hooks.patch in pp_device.h).
 # Ablation builds of the 16-row halo kernel (conv_halo_tall.hip -DPP_ABLATE=<mask>: 1 no MFMA, 2 no pixel loads, 4 no weight
 # copies, 16 no LDS fragment reads, 32 no barriers, 64 no pixel split/store).  --build here (CPU); without arguments on the MI355X.
 cd "$(dirname "$0")/.."
