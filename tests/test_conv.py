@@ -104,7 +104,7 @@ def test_conv2d_matches_torch(be, tile):
     env["PP_CONV_KSPLIT"] = "0"
     if tile == "halo":             # ... or the halo-tile kernel for every eligible PP_F32X2 geometry, whatever its size
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
-    if tile == "halo_rt":          # ... with the runtime-tap kernels also where a compile-time-tap form exists
+    if tile == "halo_rt":          # ... with the runtime-tap f16 kernels also where a compile-time-tap form exists (PP_F32X2: flat kernel)
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force", PP_CONV_HALO_CT="0")
     if tile == "ksplit":           # ... or the in-work-group split-K kernel for every f16 problem with >= 4 chunks
         env.update(PP_CONV_TILE="large", PP_CONV_KSPLIT="force")
