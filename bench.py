@@ -53,9 +53,8 @@ PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32x2": 2500.0 / 3.0, "direct": 157
 KERNEL_NAME = {"f32": "conv_igemm_kernel<float> (pp_conv2d, f32 MFMA implicit GEMM)",
                "f16": "conv_halo_f16_ct_kernel + conv_halo_f16_kernel + conv_igemm_kernel<f16> + conv_ksplit_kernel (pp_conv2d, f16 MFMA "
                       "implicit GEMM)",
-               "f32x2": "conv_halo_split_ct_kernel + conv_halo_split_kernel + conv_split_kernel (pp_conv2d PP_F32X2: f32 implicit GEMM as 3 "
-                        "f16 MFMA products; halo-tile form with compile-time taps for the 3x3 / 1x5 / 5x1 convolutions, runtime-tap "
-                        "halo tiles for other stride-1 multi-tap shapes, flat tiles for the rest)",
+               "f32x2": "conv_halo_split_ct_kernel + conv_split_kernel (pp_conv2d PP_F32X2: f32 implicit GEMM as 3 f16 MFMA products; "
+                        "halo-tile form with compile-time taps for the 3x3 / 1x5 / 5x1 convolutions, flat tiles for the rest)",
                "direct": "conv_small_cout_kernel (pp_conv2d, <= 4 output channels: fp32 FMAs on the vector ALU)"}
 
 

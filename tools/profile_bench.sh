@@ -13,7 +13,7 @@ timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $S -o fetch -- python b
 python tools/rocpd_pmc_stats.py $S/fetch_results.db FETCH_SIZE $O/pmc_fetch_size.json > /dev/null
 timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $S -o write -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $O/write.log 2>&1
 python tools/rocpd_pmc_stats.py $S/write_results.db WRITE_SIZE $O/pmc_write_size.json > /dev/null
-python tools/make_traffic.py $O/pmc_fetch_size.json $O/pmc_write_size.json $O/traffic.json conv_split_kernel=f32x2 conv_halo_split_kernel=f32x2 conv_halo_split_ct_kernel=f32x2 \
+python tools/make_traffic.py $O/pmc_fetch_size.json $O/pmc_write_size.json $O/traffic.json conv_split_kernel=f32x2 conv_halo_split_ct_kernel=f32x2 \
   conv_igemm_kernelIDF16_=f16 conv_halo_f16_kernel=f16 conv_halo_f16_ct_kernel=f16 conv_ksplit_kernel=f16 'conv_igemm_kernel<float'=f32 \
   window_attention_f16_kernel=attention corr_lookup_kernel=corr_lookup > /dev/null
 cp $O/traffic.json profiles/${TAG}_traffic.json   # bench.py reads the newest profiles/r*_traffic.json for roofline.traffic
