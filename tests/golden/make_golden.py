@@ -220,6 +220,8 @@ def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_len
     image, mask = synth.synthetic_clip(T, H, W)
     if mask_kind == "moving":
         mask = synth.moving_mask(T, H, W)
+    elif mask_kind in ("none", "full"):     # nothing to inpaint / everything to inpaint
+        mask = torch.zeros_like(mask) if mask_kind == "none" else torch.ones_like(mask)
     common = dict(mask_dilates=mask_dilates, flow_mask_dilates=flow_mask_dilates, ref_stride=ref_stride,
                   neighbor_length=neighbor_length, subvideo_length=subvideo_length, raft_iter=raft_iter, fp16="disable")
     t0 = time.time()
@@ -297,6 +299,31 @@ NODE_CASES = {
 }
 
 
+# The corners of the node's parameter ranges (propainter_nodes.py:44-79: neighbor_length 2..300, ref_stride 1..100, subvideo_length
+# 1..300, raft_iter 1..100, dilations 0..100; check_inputs: at least 2 frames) on 128x128 clips (RAFT's lower size limit): the
+# reference accepts every one of them, so must the drop-in (tests/test_edge_cases.py).
+_EDGE = dict(kind="inpaint", H=128, W=128, width=128, height=128, raft_iter=2, neighbor_length=4, ref_stride=2, subvideo_length=80,
+             mask_dilates=2, flow_mask_dilates=3)
+EDGE_CASES = {
+    "edge_T2_min": dict(_EDGE, T=2, neighbor_length=2, ref_stride=1, raft_iter=1, mask_dilates=0, flow_mask_dilates=0),
+    "edge_T3_odd_nl_no_refs": dict(_EDGE, T=3, neighbor_length=3, ref_stride=100),      # odd window, no reference frame but 0
+    "edge_T7_nl300": dict(_EDGE, T=7, neighbor_length=300, ref_stride=3),               # one window spans the clip
+    "edge_T6_sv1": dict(_EDGE, T=6, subvideo_length=1),                                 # 1-frame sub-videos (halos only)
+    "edge_T6_sv2": dict(_EDGE, T=6, subvideo_length=2),
+    "edge_T9_sv8": dict(_EDGE, T=9, subvideo_length=8),                                 # T = subvideo_length + 1
+    "edge_T8_sv8": dict(_EDGE, T=8, subvideo_length=8),                                 # T = subvideo_length (global mode)
+    "edge_T5_ragged": dict(_EDGE, T=5, H=136, W=200, width=200, height=136),            # 34x50 tokens: partial windows both ways
+    "edge_T5_nl5": dict(_EDGE, T=5, neighbor_length=5, ref_stride=1),                   # every frame a reference frame
+    "edge_T4_no_mask": dict(_EDGE, T=4, mask_kind="none"),                              # nothing to inpaint (dilation keeps 0)
+    "edge_T4_full_mask": dict(_EDGE, T=4, mask_kind="full"),                            # nothing known
+    "edge_T4_dil100": dict(_EDGE, T=4, mask_dilates=100, flow_mask_dilates=100),        # dilation swallows the frame
+    "edge_T4_outpaint_h": dict(_EDGE, kind="outpaint", T=4, width_scale=1.0, height_scale=1.5),
+    "edge_T4_outpaint_both": dict(_EDGE, kind="outpaint", T=4, width_scale=1.3, height_scale=1.1),
+    "edge_T4_outpaint_none": dict(_EDGE, kind="outpaint", T=4, width_scale=1.0, height_scale=1.0),  # scale 1: empty border
+}
+NODE_CASES.update(EDGE_CASES)
+
+
 CASES = {
     # small end-to-end clip, global reference frames (T <= subvideo_length)
     "e2e_small": dict(T=6, H=128, W=144, raft_iter=3, neighbor_length=4, ref_stride=2, subvideo_length=80,
@@ -320,7 +347,7 @@ def main():
         if args.case in ("all", name):
             run_case(name, save=not args.no_save, **kw)
     for name, kw in NODE_CASES.items():
-        if args.case in ("all", name):
+        if args.case in ("all", name) or (args.case == "edge" and name in EDGE_CASES):
             run_node_case(name, save=not args.no_save, check_oracle=not args.no_oracle, **kw)
 
 

@@ -39,19 +39,8 @@ import numpy as np
 import pytest
 import torch
 
-from comfyui_propainter_nodes_amd import nodes, pipeline, synth
-
-GOLD = Path(__file__).parent / "golden"
-
-
-def psnr(a, b, peak=255.0):
-    mse = float(((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean())
-    return 99.0 if mse == 0 else 10 * np.log10(peak * peak / mse)
-
-
-def _unpack(bits, shape):
-    n = int(np.prod(shape))
-    return np.unpackbits(bits)[:n].reshape(shape)
+from comfyui_propainter_nodes_amd import pipeline, synth
+from node_case import check_node_case, psnr
 
 
 @pytest.fixture()
@@ -66,76 +55,7 @@ def synthetic_models(monkeypatch):
 @pytest.mark.parametrize("fp16", ["enable", "disable"])
 @pytest.mark.parametrize("case", ["cfg1_node", "cfg2_24f_node", "cfg3_12f_node", "cfg2_80f_node", "cfg4_100f_node", "mov_20f_node"])
 def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
-    if not (GOLD / f"{case}.npz").exists():
-        pytest.skip(f"{case}.npz not minted")
-    g = np.load(GOLD / f"{case}.npz")
-    P = json.loads(str(g["params_json"]))
-    kind = str(g["kind"])
-    image, mask = synth.synthetic_clip(P["T"], P["H"], P["W"])
-    if P.get("mask_kind", "static") == "moving":
-        mask = synth.moving_mask(P["T"], P["H"], P["W"])
-    common = {k: P[k] for k in ("mask_dilates", "flow_mask_dilates", "ref_stride", "neighbor_length", "subvideo_length",
-                                "raft_iter")}
-    nodes.TRACE = tr = {}
-    try:
-        if kind == "inpaint":
-            out_img, out_a, out_b = nodes.ProPainterInpaint().propainter_inpainting(image, mask, P["width"], P["height"],
-                                                                                    fp16=fp16, **common)
-        else:
-            out_img, out_a, ow, oh = nodes.ProPainterOutpaint().propainter_outpainting(
-                image, P["width"], P["height"], P["width_scale"], P["height_scale"], fp16=fp16, **common)
-            assert [ow, oh] == [int(v) for v in g["out_wh"]]
-            out_b = None
-    finally:
-        nodes.TRACE = None
-    h, w = [int(v) for v in g["hw"]]
-    T = P["T"]
-    assert out_img.dtype == torch.float32 and tuple(out_img.shape) == (T, h, w, 3) and not out_img.is_cuda
-    # ---- node mask outputs: bit-exact ------------------------------------------------------------------------------
-    md = _unpack(g["masks_dilated"], (T, h, w))
-    fm = _unpack(g["flow_masks"], (T, h, w))
-    assert np.array_equal(tr["flow_masks"].cpu().numpy(), fm) and np.array_equal(tr["masks_dilated"].cpu().numpy(), md)
-    assert tuple(out_a.shape) == tuple(int(v) for v in g["out_a_shape"])
-    assert np.array_equal((out_a.cpu().numpy() > 0.5).astype(np.uint8), _unpack(g["out_a"], tuple(out_a.shape)))
-    if out_b is not None:
-        assert np.array_equal((out_b.cpu().numpy() > 0.5).astype(np.uint8), _unpack(g["out_b"], tuple(out_b.shape)))
-    # ---- stage tensors ---------------------------------------------------------------------------------------------
-    s = P["flow_stride"]
-    gt = tr["gt_flows"].cpu()[:, :, ::2 * s, ::2 * s].permute(0, 1, 4, 2, 3).numpy()      # [2,T-1,2,h/2s,w/2s]
-    e_gt = float(np.abs(gt - g["gt_flow"]).max())
-    pf = tr["pred_flows"].cpu()[:, :, ::s, ::s].permute(0, 1, 4, 2, 3).numpy()
-    d_pf = np.abs(pf - g["pred_flow"].astype(np.float32))
-    e_pf, q_pf, m_pf = float(d_pf.max()), float(np.quantile(d_pf, 0.999)), float(d_pf.mean())
-    # outside the flow mask the completed flow IS the RAFT flow (combine_flow, recurrent_flow_completion.py:389-400):
-    # forward flows use the masks of frames 0..T-2, backward flows those of frames 1..T-1
-    fms = fm[:, ::s, ::s].astype(bool)
-    hole = np.stack([fms[:-1], fms[1:]], 0)[:, :, None]                                   # [2,T-1,1,h/s,w/s]
-    # (the fixture stores them as f16: half an ulp = 2^-11 relative, on flows of up to tens of px)
-    e_out = float(((d_pf - np.abs(g["pred_flow"].astype(np.float32)) * 2.0 ** -10) * ~hole).max())
-    um = _unpack(g["updated_masks"], (T, h, w))
-    frac_m = float((tr["updated_masks"].cpu().numpy() != um).mean())
-    # ---- final frames ----------------------------------------------------------------------------------------------
-    out_u8 = (out_img.numpy() * 255 + 0.5).astype(np.uint8)
-    assert np.array_equal(out_u8.astype(np.float32) / 255.0, out_img.numpy())                # values are exactly k/255
-    sel = md.astype(bool)
-    frames_in = tr["frames_u8"].cpu().numpy()
-    assert np.array_equal(out_u8[~sel], frames_in[~sel])                                     # untouched outside the mask
-    got, want = out_u8[sel], g["out_masked"]
-    p = psnr(got, want)
-    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
-    frac2 = float((diff > 2).mean())
-    print(f"{case} fp16={fp16}: gt_flow {e_gt:.2e} px, pred_flow max {e_pf:.2e} (outside the hole {e_out:.2e}) p99.9 {q_pf:.2e} mean {m_pf:.2e} px, upd_mask_frac {frac_m:.2e}, masked-pixel PSNR {p:.1f} dB, "
-          f"max {int(diff.max())} LSB, frac>2LSB {frac2:.2e}")
-    assert e_gt < 2e-3
-    assert e_out < 2e-3                              # = the RAFT-flow bound, beyond the fixture's f16 storage rounding
-    if T > 40:                                       # chaotic inside the hole (see the module docstring)
-        assert m_pf < 0.25 and e_pf < 10.0
-    elif fp16 == "disable":
-        assert e_pf < 5e-2 and m_pf < 5e-3
-    else:
-        assert m_pf < 5e-2 and e_pf < 3.0
-    assert frac_m < 5e-3
-    assert p >= 40.0 and frac2 < 1e-2
+    check_node_case(case, fp16)
 
 
 @pytest.mark.gpu

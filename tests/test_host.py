@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from comfyui_propainter_nodes_amd import image_utils, nodes, pipeline
+from comfyui_propainter_nodes_amd import image_utils, nodes, pipeline, synth
 
 GOLD = Path(__file__).parent / "golden"
 
@@ -52,6 +52,17 @@ def test_check_inputs_errors():
     with pytest.raises(Exception, match="same dimensions"):
         nodes.check_inputs(torch.zeros(4, 8, 8, 3), torch.zeros(1, 8, 9))
     nodes.check_inputs(torch.zeros(4, 8, 8, 3), torch.zeros(1, 8, 8))
+
+
+def test_zero_size_fails_like_the_reference():
+    """width / height 0 are inside INPUT_TYPES' range (min 0, propainter_nodes.py:50-51) and the reference fails on them in
+    PIL's resize (utils/image_utils.py:184 -> "height and width must be > 0", observed by running its node); so does the
+    drop-in -- also when only one side rounds down to 0 (7 -> 0)."""
+    image, mask = synth.synthetic_clip(3, 132, 150)
+    for wh in ((0, 0), (7, 300)):
+        cfg = image_utils.ImageConfig(*wh, 2, 3, (150, 132), 3)
+        with pytest.raises(ValueError, match="height and width must be > 0"):
+            image_utils.prepare_frames_and_masks(image_utils.image_to_uint8_frames(image), mask, cfg)
 
 
 def test_sizes_round_down_to_multiples_of_8():
