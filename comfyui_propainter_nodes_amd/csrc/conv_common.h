@@ -391,6 +391,8 @@ int launch_igemm_ff(void* stream, const ConvK& k, int Z);                 // f32
 int launch_igemm_fh(void* stream, const ConvK& k, int Z);                 // f32 tensors, f16 output
 // f32 convolution on the f16 matrix pipe (PP_F32X2): conv_split.hip
 int launch_split(void* stream, const ConvK& k, int Z);
+// conv_igemm.hip: parameter block -> kernel arguments with the shared argument checks
+int convk_from_params(const pp_conv2d_params* p, ConvK* k, const char* who, bool virtual_input);
 // f16 convolutions with few output pixels and a long reduction (conv_ksplit.hip); returns 1 when not eligible
 int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // ... and its halo-tile form for stride-1 multi-tap convolutions (conv_halo.hip); returns 1 when not eligible

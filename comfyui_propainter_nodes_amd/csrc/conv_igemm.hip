@@ -4,29 +4,41 @@
 // conv_direct.hip.
 #include "conv_common.h"
 
-extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
-  using namespace pp;
-  if (!p) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: null params");
-  if (p->nseg < 1 || p->nseg > PP_MAX_SEG) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: nseg out of range");
+#include <stdio.h>
+
+namespace pp {
+
+static int fail2(int code, const char* who, const char* what) {
+  char msg[192];
+  snprintf(msg, sizeof(msg), "%s: %s", who, what);
+  return pp_fail(code, msg);
+}
+
+// pp_conv2d_params -> kernel-argument block, with the argument checks every entry point that takes the block shares
+// (`who` prefixes the error text; `virtual_input`: the input segments describe a tensor that is never materialised -- the
+// sampled columns of pp_deform_conv -- so their pointers are not looked at)
+int convk_from_params(const pp_conv2d_params* p, ConvK* kp, const char* who, bool virtual_input) {
+  ConvK& k = *kp;
+  if (!p) return fail2(PP_ERR_BAD_ARG, who, "null params");
+  if (p->nseg < 1 || p->nseg > PP_MAX_SEG) return fail2(PP_ERR_BAD_ARG, who, "nseg out of range");
   if (p->dtype != PP_F32 && p->dtype != PP_F16 && p->dtype != PP_F32X2)
-    return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: dtype");
-  if (p->out_dtype != PP_F32 && p->out_dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: out_dtype");
-  if (!p->weight || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: null weight/out");
-  if (p->Z < 1 || p->Z > 65535) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: Z out of range");
-  if (p->epi != PP_EPI_NONE && !p->aux1) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: epilogue needs aux1");
-  if (p->epi == PP_EPI_GRU && !p->aux2) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: GRU epilogue needs aux2");
+    return fail2(PP_ERR_UNSUPPORTED, who, "dtype");
+  if (p->out_dtype != PP_F32 && p->out_dtype != PP_F16) return fail2(PP_ERR_UNSUPPORTED, who, "out_dtype");
+  if (!p->weight || !p->out) return fail2(PP_ERR_BAD_ARG, who, "null weight/out");
+  if (p->Z < 1 || p->Z > 65535) return fail2(PP_ERR_BAD_ARG, who, "Z out of range");
+  if (p->epi != PP_EPI_NONE && !p->aux1) return fail2(PP_ERR_BAD_ARG, who, "epilogue needs aux1");
+  if (p->epi == PP_EPI_GRU && !p->aux2) return fail2(PP_ERR_BAD_ARG, who, "GRU epilogue needs aux2");
   const int epp = p->dtype == PP_F16 ? 8 : 4;
-  ConvK k;
   memset(&k, 0, sizeof(k));
   int cpt = 0;
   for (int s = 0; s < p->nseg; ++s) {
-    if (!p->in_ptr[s]) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: null input segment");
+    if (!virtual_input && !p->in_ptr[s]) return fail2(PP_ERR_BAD_ARG, who, "null input segment");
     if (p->in_C[s] <= 0 || (p->in_C[s] % epp) != 0)
-      return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: segment channels must be a positive multiple of 16 bytes");
+      return fail2(PP_ERR_BAD_ARG, who, "segment channels must be a positive multiple of 16 bytes");
     if ((p->in_ldc[s] % epp) != 0 || (p->in_zoff[s] % epp) != 0)
-      return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: segment pitch / z offset must be 16-byte multiples");
-    if ((reinterpret_cast<uintptr_t>(p->in_ptr[s]) & 15) != 0)
-      return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: segment base must be 16-byte aligned");
+      return fail2(PP_ERR_BAD_ARG, who, "segment pitch / z offset must be 16-byte multiples");
+    if (!virtual_input && (reinterpret_cast<uintptr_t>(p->in_ptr[s]) & 15) != 0)
+      return fail2(PP_ERR_BAD_ARG, who, "segment base must be 16-byte aligned");
     k.in_ptr[s] = p->in_ptr[s];
     k.in_C[s] = (int)p->in_C[s];
     k.in_ldc[s] = (int)p->in_ldc[s];
@@ -35,12 +47,12 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
     cpt += k.seg_chunks[s];
   }
   if ((reinterpret_cast<uintptr_t>(p->weight) & 15) != 0)
-    return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: weight must be 16-byte aligned");
+    return fail2(PP_ERR_BAD_ARG, who, "weight must be 16-byte aligned");
   k.nseg = p->nseg;
   k.N = (int)p->N; k.H = (int)p->H; k.W = (int)p->W; k.Ho = (int)p->Ho; k.Wo = (int)p->Wo;
   k.kh = p->kh; k.kw = p->kw; k.sh = p->sh; k.sw = p->sw; k.ph = p->ph; k.pw = p->pw; k.dh = p->dh; k.dw = p->dw;
   if (k.kh < 1 || k.kw < 1 || k.sh < 1 || k.sw < 1 || k.dh < 1 || k.dw < 1)
-    return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: bad kernel geometry");
+    return fail2(PP_ERR_BAD_ARG, who, "bad kernel geometry");
   k.pad_mode = p->pad_mode;
   k.weight = p->weight; k.w_zoff = p->w_zoff;
   k.chunks_per_tap = cpt;
@@ -49,19 +61,29 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   k.bias = reinterpret_cast<const float*>(p->bias); k.bias_zoff = p->bias_zoff;
   k.Cout = (int)p->Cout;
   k.M = p->N * p->Ho * p->Wo;
-  if (k.M <= 0 || k.Cout <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: empty problem");
+  if (k.M <= 0 || k.Cout <= 0) return fail2(PP_ERR_BAD_ARG, who, "empty problem");
   k.out = p->out; k.out_ldc = (int)p->out_ldc; k.out_zoff = p->out_zoff;
   k.act = p->act; k.act2 = p->act2; k.act_split = p->act_split;
   k.act_param = p->act_param; k.out_scale = p->out_scale;
   k.epi = p->epi;
   if (p->epi_from < 0 || (p->epi_from & 3) != 0 || (p->epi_from != 0 && p->epi_from >= p->Cout))
-    return pp_fail(PP_ERR_BAD_ARG, "pp_conv2d: epi_from must be a multiple of 4 below Cout");
+    return fail2(PP_ERR_BAD_ARG, who, "epi_from must be a multiple of 4 below Cout");
   k.epi_from = p->epi == PP_EPI_NONE ? 0 : (int)p->epi_from;
   k.aux1 = p->aux1; k.aux1_ldc = (int)p->aux1_ldc; k.aux1_zoff = p->aux1_zoff;
   k.aux2 = p->aux2; k.aux2_ldc = (int)p->aux2_ldc; k.aux2_zoff = p->aux2_zoff;
   k.pre_add = p->pre_add; k.pre_add_ldc = (int)p->pre_add_ldc;
   k.weight_f32 = reinterpret_cast<const float*>(p->weight_f32);
-  if (p->pre_add && p->Z != 1) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: pre_add with Z > 1");
+  if (p->pre_add && p->Z != 1) return fail2(PP_ERR_UNSUPPORTED, who, "pre_add with Z > 1");
+  return PP_OK;
+}
+
+}  // namespace pp
+
+extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
+  using namespace pp;
+  ConvK k;
+  const int bad = convk_from_params(p, &k, "pp_conv2d", false);
+  if (bad != PP_OK) return bad;
   const int Z = (int)p->Z;
   if (k.Cout <= 4) {  // 2-3 output channels on a 32-channel MFMA tile are wasted matrix work: streaming vector-ALU kernel
     const int rd = launch_direct_small_cout(stream, k, Z, p->dtype, p->out_dtype == PP_F16);

@@ -88,6 +88,8 @@ __device__ __forceinline__ void wait_vmcnt_hidden() {
 }
 // LDS writes / reads of this wave retired (what __syncthreads() would wait for besides vmcnt)
 __device__ __forceinline__ void pp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// the instruction scheduler moves nothing across this point (emits no code)
+__device__ __forceinline__ void pp_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void pp_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -103,6 +105,7 @@ static const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
 template <int N>
 inline void pp_wait_vmcnt() {}
 inline void pp_wait_lgkm0() {}
+inline void pp_sched_fence() {}
 inline void gload16_hidden(f4& dst, const void* src) { memcpy(&dst, src, 16); }
 inline void gload16_hidden_s(f4& dst, const void* sbase, uint32_t byte_off) { memcpy(&dst, static_cast<const char*>(sbase) + byte_off, 16); }
 template <int N>

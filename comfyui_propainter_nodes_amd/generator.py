@@ -220,7 +220,8 @@ class InpaintGeneratorMI355:
         mp = torch.stack([gather(maskpair, i) for i in range(lt)], 0)      # [lt,nw,h,w,8]
         t128, u128, warped, aligned = buf(128), buf(128), buf(128), buf(128)
         om = buf(432, torch.float32)
-        cols = buf(9 * 128)
+        fused = self.dt == torch.float16 and ops.deform_fused()
+        cols = None if fused else buf(9 * 128)
         outs = {}
         src = x
         for name in ("backward_1", "forward_1"):
@@ -242,8 +243,11 @@ class InpaintGeneratorMI355:
                     ops.conv2d(S["off2"], [t128], u128, act="leaky", act_param=0.1)
                     ops.conv2d(S["off4"], [u128], t128, act="leaky", act_param=0.1)
                     ops.conv2d(S["off6"], [t128], om, act="tanh", out_scale=3.0, act2="sigmoid", act_split=288)
-                    ops.deform_cols(prop, None, om, cols, flow=flow)
-                    ops.conv2d(S["dcn"], [cols], aligned)
+                    if cols is None:   # one launch, no column tensor (pp_deform_conv)
+                        ops.deform_conv(S["dcn"], prop, None, om, aligned, flow=flow)
+                    else:
+                        ops.deform_cols(prop, None, om, cols, flow=flow)
+                        ops.conv2d(S["dcn"], [cols], aligned)
                     prop = aligned
                 ops.conv2d(S["bb0"], [cur, prop, mp[idx]], t128, act="leaky", act_param=0.2)
                 ops.conv2d(S["bb2"], [t128], out[idx], epi="add", aux1=prop)

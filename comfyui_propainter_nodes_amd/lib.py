@@ -119,6 +119,13 @@ class Library:
             raise RuntimeError(f"{fname} failed ({rc}): {self.cdll.pp_last_error().decode()}")
 
 
+    def call2(self, fname: str, stream, p1, p2) -> None:
+        """Entry points that take two parameter blocks (pp_deform_conv: the sampling block and the convolution block)."""
+        rc = getattr(self.cdll, fname)(ctypes.c_void_p(stream), ctypes.byref(p1), ctypes.byref(p2))
+        if rc != 0:
+            raise RuntimeError(f"{fname} failed ({rc}): {self.cdll.pp_last_error().decode()}")
+
+
 _lib: Library | None = None
 
 

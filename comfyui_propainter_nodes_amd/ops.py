@@ -238,13 +238,12 @@ def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, 
                     sum(seg_valid) if seg_valid else cin_g, split, table)
 
 
-def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
-           act2=None, act_split=0, out_scale=0.0, epi=None, aux1=None, aux2=None, pre_add=None, epi_from=0,
-           in_zoff: list[int] | None = None, out_zoff: int | None = None) -> torch.Tensor:
-    """Launch pp_conv2d.  `inputs` are channels-last views (the K segments), `out` a
-    channels-last view `[N, Ho, Wo, >=Cout*groups]` that receives the result."""
-    L = _lib.current()
-    check_device(*inputs, out, aux1, aux2, pre_add, spec.weight)
+def _conv2d_params(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
+                   act2=None, act_split=0, out_scale=0.0, epi=None, aux1=None, aux2=None, pre_add=None, epi_from=0,
+                   in_zoff: list[int] | None = None, out_zoff: int | None = None, virtual_input: bool = False):
+    """Fill a pp_conv2d_params block.  `virtual_input`: the inputs only describe a shape (meta tensors) -- the block goes
+    to pp_deform_conv, which produces the input columns on the fly."""
+    check_device(*([] if virtual_input else inputs), out, aux1, aux2, pre_add, spec.weight)
     P = _lib.STRUCTS["pp_conv2d_params"]()
     x0 = inputs[0]
     n, h, w, _, _ = nhwc_view(x0)
@@ -266,7 +265,7 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
         cs = spec.seg_channels[s]
         if tc != cs * g:
             raise ValueError(f"segment {s}: expected {cs * g} channels, got {tc}")
-        P.in_ptr[s] = t.data_ptr()
+        P.in_ptr[s] = None if virtual_input else t.data_ptr()
         P.in_C[s] = cs
         P.in_ldc[s] = ldc
         P.in_zoff[s] = in_zoff[s] if in_zoff is not None else (cs if g > 1 else 0)
@@ -312,6 +311,19 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act
             raise TypeError("pre_add dtype must match out dtype")
         P.pre_add = pre_add.data_ptr()
         P.pre_add_ldc = nhwc_view(pre_add)[4]
+    return P
+
+
+def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, aux1=None, aux2=None, pre_add=None,
+           **kw) -> torch.Tensor:
+    """Launch pp_conv2d.  `inputs` are channels-last views (the K segments), `out` a
+    channels-last view `[N, Ho, Wo, >=Cout*groups]` that receives the result.  Keywords: _conv2d_params."""
+    L = _lib.current()
+    P = _conv2d_params(spec, inputs, out, aux1=aux1, aux2=aux2, pre_add=pre_add, **kw)
+    x0 = inputs[0]
+    n, h, w, _, _ = nhwc_view(x0)
+    ho, wo = spec.out_hw(h, w)
+    g = spec.groups
     if CONV_PROFILE is not None and out.is_cuda:
         flops = 2.0 * n * ho * wo * spec.cout * g * spec.cin_valid * spec.kh * spec.kw
         key = "f16" if x0.dtype == torch.float16 else ("f32x2" if spec.split else "f32")
@@ -523,26 +535,65 @@ def deform_cols(x0: torch.Tensor, x1: torch.Tensor | None, om: torch.Tensor, col
                 flow: torch.Tensor | None = None) -> torch.Tensor:
     """Sampling half of the modulated deformable 3x3 conv: cols [N,H,W,9*Cin] (tap-major)."""
     check_device(x0, x1, om, cols, flow)
+    P, cin = _deform_cols_params(x0, x1, om, dg, flow)
+    if cols.dtype != x0.dtype or not cols.is_contiguous() or tuple(cols.shape) != (*x0.shape[:3], 9 * cin):
+        raise ValueError("deform_cols: bad cols tensor")
+    P.cols = cols.data_ptr()
+    _call("pp_deform_cols", cols, P)
+    return cols
+
+
+DEFORM_FUSED_DEFAULT = "0"
+
+
+def deform_fused() -> bool:
+    """Whether the two recurrences run their modulated deformable convolution as one launch (pp_deform_conv) or as
+    pp_deform_cols + 1x1 pp_conv2d (PP_DEFORM_FUSED=1 / 0).  Same results bit for bit either way."""
+    return os.environ.get("PP_DEFORM_FUSED", DEFORM_FUSED_DEFAULT) != "0"
+
+
+def _deform_cols_params(x0, x1, om, dg, flow):
     n, h, w, c0, l0 = nhwc_view(x0)
     P = _lib.STRUCTS["pp_deform_cols_params"]()
     P.dtype, P.dg = dtype_code(x0.dtype), dg
     P.x0, P.x0_C, P.x0_ldc = x0.data_ptr(), c0, l0
     c1 = 0
     if x1 is not None:
+        if x1.dtype != x0.dtype or tuple(x1.shape[:3]) != (n, h, w):
+            raise ValueError("deform: the two inputs must share dtype and N,H,W")
         _, _, _, c1, l1 = nhwc_view(x1)
         P.x1, P.x1_C, P.x1_ldc = x1.data_ptr(), c1, l1
-    if om.dtype != torch.float32 or om.shape[3] != 27 * dg:
-        raise ValueError("deform_cols: om must be fp32 with 27*dg channels")
+    if om.dtype != torch.float32 or om.shape[3] != 27 * dg or tuple(om.shape[:3]) != (n, h, w):
+        raise ValueError("deform: om must be fp32 [N,H,W,27*dg]")
     P.om, P.om_ldc = om.data_ptr(), nhwc_view(om)[4]
     if flow is not None:
-        if flow.dtype != torch.float32:
-            raise TypeError("deform_cols: flow must be fp32")
+        if flow.dtype != torch.float32 or tuple(flow.shape[:3]) != (n, h, w):
+            raise TypeError("deform: flow must be fp32 [N,H,W,>=2]")
         P.flow, P.flow_ldc = flow.data_ptr(), nhwc_view(flow)[4]
-    if cols.dtype != x0.dtype or not cols.is_contiguous() or tuple(cols.shape) != (n, h, w, 9 * (c0 + c1)):
-        raise ValueError("deform_cols: bad cols tensor")
-    P.cols, P.N, P.H, P.W = cols.data_ptr(), n, h, w
-    _call("pp_deform_cols", cols, P)
-    return cols
+    P.N, P.H, P.W = n, h, w
+    return P, c0 + c1
+
+
+def deform_conv(spec: ConvSpec, x0: torch.Tensor, x1: torch.Tensor | None, om: torch.Tensor, out: torch.Tensor, *,
+                dg: int = 16, flow: torch.Tensor | None = None, **kw) -> torch.Tensor:
+    """The modulated deformable 3x3 convolution in one launch (pp_deform_conv): deform_cols's sampling feeds the MFMA operand
+    of the 1x1 convolution `spec` over the 9*Cin columns directly; the column tensor is never written.  f16 tensors."""
+    check_device(x0, x1, om, flow)
+    S, cin = _deform_cols_params(x0, x1, om, dg, flow)
+    n, h, w = x0.shape[:3]
+    cols = torch.empty(n, h, w, 9 * cin, dtype=x0.dtype, device="meta")   # shape / dtype only
+    G = _conv2d_params(spec, [cols], out, virtual_input=True, **kw)
+    L = _lib.current()
+    if CONV_PROFILE is not None and out.is_cuda:
+        key = "f16"
+        if CONV_PROFILE.detailed:
+            key += f"|deform3x3 cin{cin} cout{spec.cout} g1 M{n * h * w}"
+        esz = x0.element_size()
+        nbytes = n * h * w * (cin * esz + 27 * dg * 4 + spec.cout * out.element_size()) + spec.weight.numel() * esz
+        CONV_PROFILE.launch(key, 2.0 * n * h * w * spec.cout * 9 * cin, lambda: L.call2("pp_deform_conv", stream_handle(out), S, G), nbytes)
+    else:
+        L.call2("pp_deform_conv", stream_handle(out), S, G)
+    return out
 
 
 def upsample2x(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

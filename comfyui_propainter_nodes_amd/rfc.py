@@ -123,7 +123,8 @@ class FlowCompleter:
         t128 = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
         u128 = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
         om = torch.empty(B, h, w, 432, device=dev, dtype=torch.float32)
-        cols = torch.empty(B, h, w, 9 * 256, device=dev, dtype=self.dt)
+        fused = self.dt == torch.float16 and ops.deform_fused()
+        cols = None if fused else torch.empty(B, h, w, 9 * 256, device=dev, dtype=self.dt)
         aligned = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
         for name in ("backward_", "forward_"):
             S = self.prop[name]
@@ -139,8 +140,11 @@ class FlowCompleter:
                     ops.conv2d(S["off4"], [u128], t128, act="leaky", act_param=0.1)
                     # offset = 5*tanh(first 288), mask = sigmoid(last 144)  (:36-42)
                     ops.conv2d(S["off6"], [t128], om, act="tanh", out_scale=5.0, act2="sigmoid", act_split=288)
-                    ops.deform_cols(prop, n2, om, cols)
-                    ops.conv2d(S["dcn"], [cols], aligned)
+                    if cols is None:   # one launch, no column tensor (pp_deform_conv)
+                        ops.deform_conv(S["dcn"], prop, n2, om, aligned)
+                    else:
+                        ops.deform_cols(prop, n2, om, cols)
+                        ops.conv2d(S["dcn"], [cols], aligned)
                     prop = aligned
                 segs = [cur] + ([outs["backward_"][idx]] if name == "forward_" else []) + [prop]
                 ops.conv2d(S["bb0"], segs, t128, act="leaky", act_param=0.1)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 6
+#define PP_ABI_VERSION 7
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -271,6 +271,21 @@ typedef struct {
   int64_t N, H, W;
 } pp_deform_cols_params;
 int32_t pp_deform_cols(void* stream, const pp_deform_cols_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_deform_conv -- the whole modulated deformable convolution of the same two call sites
+ * (recurrent_flow_completion.py:44-53, propainter.py:73-82: torchvision.ops.deform_conv2d with
+ * 3x3 taps, stride 1, pad 1, weight groups 1) in ONE launch: pp_deform_cols followed by the
+ * 1x1 pp_conv2d over the 9*Cin columns, without the column tensor.  It takes the two parameter
+ * blocks of that pair: `sample` as for pp_deform_cols (`cols` is ignored; f16 tensors only),
+ * `gemm` as for the 1x1 f16 pp_conv2d over [N][H][W][9*Cin] (one segment whose pointer is
+ * ignored, kh = kw = 1, Z = 1; weight packed as for that convolution, K order tap-major; bias,
+ * activations and the fused epilogue as in pp_conv2d).  The sampled values are rounded to f16
+ * exactly as pp_deform_cols stores them, so the result differs from the two-launch form only by
+ * the fp32 summation order of the kernel that would have run the 1x1 convolution.
+ * Needs Cin % 32 == 0, x0_C % 32 == 0 and (Cin/dg) % 8 == 0 (128 / 256 channels, dg 16 here).
+ * ---------------------------------------------------------------------------------- */
+int32_t pp_deform_conv(void* stream, const pp_deform_cols_params* sample, const pp_conv2d_params* gemm);
 
 /* ------------------------------------------------------------------------------------
  * pp_upsample2x -- F.interpolate(scale_factor=2, mode="bilinear", align_corners=True)

@@ -12,10 +12,12 @@ def test_header_parses_to_structs_and_functions():
     assert "pp_conv2d_params" in structs and "pp_window_attention_params" in structs
     for f in ("pp_conv2d", "pp_corr_lookup", "pp_deform_cols", "pp_img_prop_step", "pp_window_attention", "pp_compose_u8"):
         assert f in funcs
-    # every pp_<op> entry point has a matching pp_<op>_params struct
+    # every pp_<op> entry point has a matching pp_<op>_params struct (pp_deform_conv, the fused form of pp_deform_cols +
+    # pp_conv2d, takes the parameter blocks of those two)
     for f in funcs:
-        if f not in ("pp_version", "pp_last_error", "pp_struct_size", "pp_reload_options"):
+        if f not in ("pp_version", "pp_last_error", "pp_struct_size", "pp_reload_options", "pp_deform_conv"):
             assert f + "_params" in structs, f
+    assert "pp_deform_conv" in funcs
 
 
 def test_gfx950_library_builds_loads_and_exports_everything():

@@ -1,4 +1,5 @@
 """Sampling kernels against their torch formulation (oracle/ops.py restates torchvision's deform_conv2d)."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -33,6 +34,53 @@ def test_deform_conv_matches_contract(backend):
         ref = deform_conv2d(x.half().float().permute(0, 3, 1, 2), offr.permute(0, 3, 1, 2), wgt.half().float(), bias, 1, 1, 1,
                             msk.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
         err = (out.float().cpu() - ref).abs().max().item()
+        assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("tile", ["auto", "16", "32", "ksplit"])
+def test_fused_deform_conv_matches_the_two_kernel_form(backend, pp_knobs, tile):
+    """pp_deform_conv (sampling feeds the MFMA operand, no column tensor) == pp_deform_cols + 1x1 pp_conv2d: the sampled f16
+    values are the same bit for bit, so the two differ by fp32 summation order only; also against the torchvision contract
+    (oracle/ops.py).  Both call-site shapes (two 128-channel inputs / one input + flow), partial pixel tiles, offsets that leave
+    the image and non-finite offsets, every kernel form (16- / 32-pixel waves, in-work-group split K), f16 and f32 output with
+    a fused epilogue."""
+    dev = backend
+    if tile != "auto":
+        pp_knobs(PP_DEFORM_TILE=tile)
+    g = torch.Generator().manual_seed(21)
+    for c0, c1, with_flow, odt, (h, w) in ((64, 64, False, torch.float16, (9, 11)), (32, 0, True, torch.float32, (7, 5))):
+        n, dg, cout = 2, 4 if c1 == 0 else 16, 128 if c1 else 40
+        cin = c0 + c1
+        x = torch.randn(n, h, w, cin, generator=g)
+        off = torch.randn(n, h, w, 2 * dg * 9, generator=g) * 2.5
+        off[0, 1, 2, 5] = float("nan")
+        off[1, 3, 1, 7] = float("inf")
+        msk = torch.rand(n, h, w, dg * 9, generator=g)
+        flow = torch.randn(n, h, w, 2, generator=g) * 2 if with_flow else None
+        wgt = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+        bias = torch.randn(cout, generator=g)
+        om = torch.cat([off, msk], -1).to(dev)
+        xh = x.half().to(dev)
+        x0, x1 = xh[..., :c0], (xh[..., c0:] if c1 else None)
+        fl = flow.to(dev) if with_flow else None
+        spec = ops.make_conv_spec(wgt.permute(0, 2, 3, 1).reshape(cout, 9 * cin, 1, 1), bias, torch.float16).to(dev)
+        res = torch.randn(n, h, w, cout, generator=g).to(odt).to(dev)
+        cols = torch.empty(n, h, w, 9 * cin, device=dev, dtype=torch.float16)
+        ops.deform_cols(x0, x1, om, cols, dg=dg, flow=fl)
+        two = ops.conv2d(spec, [cols], torch.empty(n, h, w, cout, device=dev, dtype=odt), act="leaky", act_param=0.1, epi="add", aux1=res)
+        one = ops.deform_conv(spec, x0, x1, om, torch.empty(n, h, w, cout, device=dev, dtype=odt), dg=dg, flow=fl, act="leaky",
+                              act_param=0.1, epi="add", aux1=res)
+        scale = max(1.0, two.float().abs().max().item())
+        assert (one.float() - two.float()).abs().max().item() < (2e-3 if odt == torch.float16 else 2e-5) * scale
+        if tile == "auto":   # the default form sums in the order of the 1x1 convolution kernel it replaces
+            assert torch.equal(one, two)
+        offr = torch.nan_to_num(off, nan=-1e8, posinf=-1e8, neginf=-1e8)   # non-finite offsets sample nothing
+        if with_flow:
+            offr = offr + torch.stack([flow[..., 1], flow[..., 0]], -1).repeat(1, 1, 1, dg * 9)
+        ref = deform_conv2d(x.half().float().permute(0, 3, 1, 2), offr.permute(0, 3, 1, 2), wgt.half().float(), bias, 1, 1, 1,
+                            msk.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        ref = F.leaky_relu(ref, 0.1) + res.float().cpu()
+        err = (one.float().cpu() - ref).abs().max().item()
         assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
 
 

@@ -17,6 +17,7 @@ def test_flow_completion_stage_under_emulation(emu_lib, monkeypatch, dtype, gemm
     """f16 storage (fp16 "enable") and f32 storage (fp16 "disable": PP_F32X2 split products, or the f32 MFMA
     instructions with PP_F32_GEMM=exact) against the fp32 oracle."""
     monkeypatch.setenv("PP_F32_GEMM", gemm)
+    monkeypatch.setenv("PP_DEFORM_FUSED", "1")
     sds = weights.synth_state_dicts(0)
     T, H, W = 3, 32, 40
     g = torch.Generator().manual_seed(5)
@@ -31,3 +32,8 @@ def test_flow_completion_stage_under_emulation(emu_lib, monkeypatch, dtype, gemm
     for d in (0, 1):
         err = (out[d].permute(0, 3, 1, 2) - ref[d][0]).abs().max().item()
         assert err < tol, err  # f16 activations: 2e-2 px on flows of a few px; f32: fp32 rounding noise
+    if dtype == torch.float16:
+        # the stage ran the one-launch deformable convolution (pp_deform_conv); the two-launch form (pp_deform_cols + 1x1
+        # pp_conv2d) it replaces gives the same flows bit for bit: same sampled f16 values, same summation order
+        monkeypatch.setenv("PP_DEFORM_FUSED", "0")
+        assert torch.equal(rfc.FlowCompleter(sds["rfc"], "cpu", dtype)(flows, masks), out)
