@@ -18,6 +18,9 @@
 // is covered by occupancy.  KS > 1 (flow completion: 2 x 45 x 80 pixels, 72 chunks) splits the chunk range over KS groups
 // working on the same pixel tile -- KS chains in flight per work-group, each 1/KS as long -- and the partial accumulators
 // meet in LDS, as in conv_ksplit.hip (same chunk ranges, same summation order).  Bias / activation / fused epilogue: conv_common.h.
+// Forms: 4 waves x 32 pixels (feature propagation, 90 x 160 images), 4 waves x 16 pixels, and KS = 4 groups of 2 waves x 16
+// pixels (small images with a long reduction: conv_ksplit.hip's selection rule, so that either form of the deformable
+// convolution sums in the same order and the results are bit-identical).
 #include "conv_common.h"
 
 namespace pp {
@@ -132,16 +135,23 @@ __global__ void __launch_bounds__(KS * NW * 64) deform_conv_kernel(const DeformS
   // that does not contribute reads the first pixel of the image; deform_cols_kernel's arithmetic, same order).
   // The two inputs' per-lane bases live in registers: picking d.x0 / d.x1 inside the loop made the compiler index the
   // kernel-argument block in memory (a dependent load and a full vmcnt drain per chunk).
-  const T* const src_a = reinterpret_cast<const T*>(d.x0) + fgrp * 8;
-  const T* const src_b = d.x1 ? reinterpret_cast<const T*>(d.x1) + fgrp * 8 - d.x0_C : src_a;
+  // Per sub-tile: the image base of this lane's channel piece in either input (64-bit, once); inside the loop the corner
+  // offsets are 32-bit element offsets within one image.
   const int ldc_a = d.x0_ldc, ldc_b = d.x1 ? d.x1_ldc : d.x0_ldc, split_c = d.x0_C;
+  const T* img_a[TP];
+  const T* img_b[TP];
+#pragma unroll
+  for (int b = 0; b < TP; ++b) {
+    img_a[b] = reinterpret_cast<const T*>(d.x0) + fgrp * 8 + pimg[b] * ldc_a;
+    img_b[b] = d.x1 ? reinterpret_cast<const T*>(d.x1) + fgrp * 8 - d.x0_C + pimg[b] * ldc_b : img_a[b];
+  }
   DeformRaw raw[TP];
   auto issue_corners = [&](int q) PP_INLINE_LAMBDA {
     const int tap = q / d.cchunks;
     const int cc = q - tap * d.cchunks;
     const bool first = cc * 32 < split_c;  // wave-uniform: x0_C is a multiple of 32
-    const T* src0 = (first ? src_a : src_b) + cc * 32;
     const int ldc = first ? ldc_a : ldc_b;
+    const int rowstep = d.W * ldc;
     const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
@@ -164,29 +174,37 @@ __global__ void __launch_bounds__(KS * NW * 64) deform_conv_kernel(const DeformS
       const bool x0ok = x0 >= 0, x1ok = (x0 + 1 <= d.W - 1);
       const bool k00 = y0ok && x0ok, k01 = y0ok && x1ok, k10 = y1ok && x0ok, k11 = y1ok && x1ok;
       r.ok = (k00 ? 1 : 0) | (k01 ? 2 : 0) | (k10 ? 4 : 0) | (k11 ? 8 : 0);
-      const T* img = src0 + pimg[b] * ldc;
-      const int64_t o00 = ((int64_t)y0 * d.W + x0) * ldc;
+      const T* img = (first ? img_a[b] : img_b[b]) + cc * 32;
+      const int o00 = (y0 * d.W + x0) * ldc;   // (only used when the corner lies inside the image: no overflow)
       r.q00 = *reinterpret_cast<const h8*>(img + (k00 ? o00 : 0));
       r.q01 = *reinterpret_cast<const h8*>(img + (k01 ? o00 + ldc : 0));
-      r.q10 = *reinterpret_cast<const h8*>(img + (k10 ? o00 + (int64_t)d.W * ldc : 0));
-      r.q11 = *reinterpret_cast<const h8*>(img + (k11 ? o00 + (int64_t)d.W * ldc + ldc : 0));
+      r.q10 = *reinterpret_cast<const h8*>(img + (k10 ? o00 + rowstep : 0));
+      r.q11 = *reinterpret_cast<const h8*>(img + (k11 ? o00 + rowstep + ldc : 0));
     }
   };
 
   h8 bf[TP];
+  // deform_cols_kernel's blend (v = 0; v += w * q per contributing corner, in corner order; one rounding to f16) on channel
+  // PAIRS: the same IEEE operations per element, issued as packed fp32 multiplies / adds
   auto blend = [&]() PP_INLINE_LAMBDA {
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
       const DeformRaw& r = raw[b];
+      const bool k00 = r.ok & 1, k01 = r.ok & 2, k10 = r.ok & 4, k11 = r.ok & 8;
       h8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = 0.f;
-        if (r.ok & 1) v += r.w00 * (float)r.q00[e];
-        if (r.ok & 2) v += r.w01 * (float)r.q01[e];
-        if (r.ok & 4) v += r.w10 * (float)r.q10[e];
-        if (r.ok & 8) v += r.w11 * (float)r.q11[e];
-        o[e] = (half_t)v;
+      for (int e = 0; e < 8; e += 2) {
+        f2 v = {0.f, 0.f};
+        const f2 t00 = v + r.w00 * f2{(float)r.q00[e], (float)r.q00[e + 1]};
+        v = k00 ? t00 : v;
+        const f2 t01 = v + r.w01 * f2{(float)r.q01[e], (float)r.q01[e + 1]};
+        v = k01 ? t01 : v;
+        const f2 t10 = v + r.w10 * f2{(float)r.q10[e], (float)r.q10[e + 1]};
+        v = k10 ? t10 : v;
+        const f2 t11 = v + r.w11 * f2{(float)r.q11[e], (float)r.q11[e + 1]};
+        v = k11 ? t11 : v;
+        o[e] = (half_t)v[0];
+        o[e + 1] = (half_t)v[1];
       }
       bf[b] = o;
     }
@@ -300,7 +318,9 @@ static int launch_deform(void* stream, const DeformSrc& d, const ConvK& k) {
   // two-launch form would have: the results are bit-identical either way round)
   const int64_t img_blocks32 = (((int64_t)d.H * d.W + 31) / 32) * ((k.Cout + 127) / 128);
   const bool small_image = img_blocks32 <= 160 && k.nchunks >= 8 * 4 && k.Cout > 64;
-  if (mode == 3 || (mode == 0 && small_image)) return launch_deform_cfg<OT, 4, 4, 1>(stream, d, k);
+  // (2 waves per K group: 32-pixel work-groups of 8 waves -- 225 of them for flow completion's 7200 pixels, and 256
+  // registers per lane; 4 waves per group would be 113 work-groups capped at 128 registers, which spills)
+  if (mode == 3 || (mode == 0 && small_image)) return launch_deform_cfg<OT, 2, 4, 1>(stream, d, k);
   if (mode == 1) return launch_deform_cfg<OT, 4, 1, 1>(stream, d, k);
   return launch_deform_cfg<OT, 4, 1, 2>(stream, d, k);
 }
