@@ -20,6 +20,12 @@ from comfyui_propainter_nodes_amd import lib, ops  # noqa: E402
 
 
 def timed(fn, reps):
+    if not torch.cuda.is_available():   # --emu dry run: wall clock of the emulator, meaningless as a timing
+        import time
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) * 1e6 / reps
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -36,11 +42,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--windows", type=int, default=8)
+    ap.add_argument("--emu", action="store_true", help="dry run of this script on CPU under the x86 emulator (tiny shapes)")
     args = ap.parse_args()
-    lib.load()
-    dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(7)
     shapes = {"featprop": (args.windows, 90, 160, 128, 0, True), "rfc": (2, 45, 80, 128, 128, False)}
+    if args.emu:
+        sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests" / "emu"))
+        import emu_loader
+
+        emu_loader.load_emulator()
+        dev = torch.device("cpu")
+        shapes = {"featprop": (1, 10, 12, 128, 0, True), "rfc": (1, 9, 8, 128, 128, False)}
+    else:
+        lib.load()
+        dev = torch.device("cuda:0")
     for name, (n, h, w, c0, c1, with_flow) in shapes.items():
         cin, dg, cout = c0 + c1, 16, 128
         x = (torch.randn(n, h, w, cin, generator=g) * 0.5).half().to(dev)
