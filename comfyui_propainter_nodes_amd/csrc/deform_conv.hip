@@ -18,9 +18,10 @@
 // is covered by occupancy.  KS > 1 (flow completion: 2 x 45 x 80 pixels, 72 chunks) splits the chunk range over KS groups
 // working on the same pixel tile -- KS chains in flight per work-group, each 1/KS as long -- and the partial accumulators
 // meet in LDS, as in conv_ksplit.hip (same chunk ranges, same summation order).  Bias / activation / fused epilogue: conv_common.h.
-// Forms: 4 waves x 32 pixels (feature propagation, 90 x 160 images), 4 waves x 16 pixels, and KS = 4 groups of 2 waves x 16
-// pixels (small images with a long reduction: conv_ksplit.hip's selection rule, so that either form of the deformable
-// convolution sums in the same order and the results are bit-identical).
+// The shipped form is KS = 4 groups of 2 waves x 16 pixels, used by the host for small images with a long reduction --
+// conv_ksplit.hip's selection rule, so that either form of the deformable convolution sums in the same order and the
+// results are bit-identical.  Work-groups walk the pixels in XCD-contiguous order (pp_device.h): dealt round robin, every
+// XCD's L2 saw every feature line and the kernel ran 1.2-1.8x slower.
 #include "conv_common.h"
 
 namespace pp {
@@ -36,6 +37,7 @@ struct DeformSrc {
   int flow_ldc;
   int H, W, dg, cg;
   int cchunks;  // 32-channel chunks of the input (Cin / 32)
+  int xcd;      // work-groups in XCD-contiguous order (pp_device.h)
 };
 
 // what a lane keeps between issuing the corner loads of a chunk and blending them
@@ -65,7 +67,8 @@ __global__ void __launch_bounds__(KS * NW * 64) deform_conv_kernel(const DeformS
   const int lane = tid & 63;
   const int wave = tid >> 6;
   T* smem = smem_all + grp * NST * STAGE;
-  const int64_t p_base = (int64_t)blockIdx.x * BP;
+  const int pblk = d.xcd ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int64_t p_base = (int64_t)pblk * BP;
   const int c_base = (int)blockIdx.y * BC;
 
   // ---- weight tile: lane-linear DMA image, LDS piece slot pc of row r holds source piece pc ^ swz(r) ------------
@@ -311,18 +314,12 @@ static int launch_deform_cfg(void* stream, const DeformSrc& d, const ConvK& k) {
 
 template <typename OT>
 static int launch_deform(void* stream, const DeformSrc& d, const ConvK& k) {
-  // A function of the LAYER (image size, reduction length), never of the batch: the K split changes the summation
-  // order and a rank of a sharded run must pick the same form as the single-GPU run (cf. conv_ksplit.hip).
-  const int mode = options().deform;  // 0 auto, 1 flat 16-pixel waves, 2 flat 32-pixel waves, 3 K split
-  // (conv_ksplit.hip's rule for the 1x1 convolution this launch replaces, so that the fused form sums in the order the
-  // two-launch form would have: the results are bit-identical either way round)
-  const int64_t img_blocks32 = (((int64_t)d.H * d.W + 31) / 32) * ((k.Cout + 127) / 128);
-  const bool small_image = img_blocks32 <= 160 && k.nchunks >= 8 * 4 && k.Cout > 64;
-  // (2 waves per K group: 32-pixel work-groups of 8 waves -- 225 of them for flow completion's 7200 pixels, and 256
-  // registers per lane; 4 waves per group would be 113 work-groups capped at 128 registers, which spills)
-  if (mode == 3 || (mode == 0 && small_image)) return launch_deform_cfg<OT, 2, 4, 1>(stream, d, k);
-  if (mode == 1) return launch_deform_cfg<OT, 4, 1, 1>(stream, d, k);
-  return launch_deform_cfg<OT, 4, 1, 2>(stream, d, k);
+  // One form ships: 4 K groups of 2 waves on 32 pixels (8 waves, 225 work-groups for flow completion's 7200 pixels, 256
+  // registers per lane; 4-wave groups would be 113 work-groups capped at 128 registers, which spills).  Measured on the
+  // MI355X (profiles/r03_deform_fusion.md): 46.9 us against 54.3 us for pp_deform_cols + pp_conv2d at flow completion's
+  // shape; at feature propagation's 8 x 90 x 160 pixels it is 378 us against 358 us (the flat forms -- 4 waves x 16 / 32
+  // pixels, no K split: 410 / 489 us -- are not instantiated), so the host keeps the two launches there (ops.deform_fused).
+  return launch_deform_cfg<OT, 2, 4, 1>(stream, d, k);
 }
 
 }  // namespace pp
@@ -352,5 +349,6 @@ extern "C" int32_t pp_deform_conv(void* stream, const pp_deform_cols_params* s, 
       (d.x1 && (reinterpret_cast<uintptr_t>(d.x1) & 15) != 0))
     return pp_fail(PP_ERR_BAD_ARG, "pp_deform_conv: inputs must be 16-byte aligned with 16-byte pitches");
   d.cchunks = (int)(Cin / 32);
+  d.xcd = options().deform_xcd && k.Cout <= 128;  // (grid.y == 1: blockIdx.x alone decides the XCD)
   return g->out_dtype == PP_F16 ? launch_deform<half_t>(stream, d, k) : launch_deform<float>(stream, d, k);
 }

@@ -59,8 +59,8 @@ static void load_options() {
     else if (e[0] == 'c') o.tile = 6;
     else o.tile = e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
   }
-  o.deform = 0;
-  if (const char* e = getenv("PP_DEFORM_TILE")) o.deform = e[0] == '1' ? 1 : (e[0] == '3' ? 2 : (e[0] == 'k' ? 3 : 0));
+  o.deform_xcd = 1;
+  if (const char* e = getenv("PP_DEFORM_XCD")) o.deform_xcd = e[0] != '0';
   g_options = o;
   g_options_loaded = true;
 }

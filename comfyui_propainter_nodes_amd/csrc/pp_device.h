@@ -30,6 +30,19 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
+// XCD-aware work-group order: the hardware deals the work-groups of a 1-D grid to the 8 XCDs round robin (id & 7), each
+// XCD with its own 4 MiB L2.  Logical block L makes XCD x process a CONTIGUOUS eighth of the blocks, so neighbouring
+// blocks -- which read neighbouring pixels -- share an L2 instead of spreading every line over all eight.
+#ifdef PP_EMU
+inline
+#else
+__device__ __forceinline__
+#endif
+int xcd_contiguous_block(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 constexpr int kWave = 64;
 
 // ---------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@
 //   PP_CONV_TILE     large | small | xlforce | tiny | classic   pin one flat-tile family
 //   PP_CONV_DIRECT   0 | force   <= 4-output-channel streaming kernel off / regardless of the image size
 //   PP_CONV_TRACE    (set)       print which convolution kernel family ran (debugging aid)
-//   PP_DEFORM_TILE   16 | 32 | ksplit   pin one form of pp_deform_conv (16- / 32-pixel waves, in-work-group split K)
+//   PP_DEFORM_XCD    0           pp_deform_cols / pp_deform_conv walk their pixel blocks in launch order instead of XCD-contiguous order
 #pragma once
 
 namespace pp {
@@ -18,7 +18,7 @@ struct Options {
   int tile;     // 0 auto, 1 large, 2 small, 4 xlforce, 5 tiny, 6 classic
   int direct;   // 0 off, 1 auto, 2 force
   int trace;
-  int deform;   // 0 auto, 1 flat 16-pixel waves, 2 flat 32-pixel waves, 3 split K
+  int deform_xcd;  // 1 (default): the deformable-sampling kernels walk their pixel blocks in XCD-contiguous order
 };
 const Options& options();
 }  // namespace pp

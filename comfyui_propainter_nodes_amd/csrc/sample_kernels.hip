@@ -3,6 +3,7 @@
 // flow-completion input/output elementwise passes.  Contracts: include/propainter_mi355.h.
 #include "pp_device.h"
 #include "pp_host.h"
+#include "pp_options.h"
 
 namespace pp {
 
@@ -23,11 +24,13 @@ struct DeformK {
   void* cols;
   int H, W, dg, cg, Cin;
   int64_t total;
+  int xcd;  // work-groups in XCD-contiguous order (pp_device.h)
 };
 
 template <typename T>
 __global__ void __launch_bounds__(256) deform_cols_kernel(const DeformK k) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int blk = k.xcd ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int64_t idx = (int64_t)blk * 256 + threadIdx.x;
   if (idx >= k.total) return;
   const int g = (int)(idx % k.dg);
   const int64_t t = idx / k.dg;
@@ -236,6 +239,7 @@ extern "C" int32_t pp_deform_cols(void* stream, const pp_deform_cols_params* p) 
   if (k.x0_C % k.cg != 0) return pp_fail(PP_ERR_BAD_ARG, "pp_deform_cols: a deformable group straddles the two inputs");
   k.total = p->N * p->H * p->W * 9 * k.dg;
   if (k.total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_deform_cols: empty problem");
+  k.xcd = options().deform_xcd;
   if (p->dtype == PP_F16) {
     PP_LAUNCH((deform_cols_kernel<half_t>), dim3(nblk(k.total)), dim3(256), 0, stream, k);
   } else {

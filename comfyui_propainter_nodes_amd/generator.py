@@ -220,7 +220,7 @@ class InpaintGeneratorMI355:
         mp = torch.stack([gather(maskpair, i) for i in range(lt)], 0)      # [lt,nw,h,w,8]
         t128, u128, warped, aligned = buf(128), buf(128), buf(128), buf(128)
         om = buf(432, torch.float32)
-        fused = self.dt == torch.float16 and ops.deform_fused()
+        fused = self.dt == torch.float16 and ops.deform_fused(h, w)
         cols = None if fused else buf(9 * 128)
         outs = {}
         src = x

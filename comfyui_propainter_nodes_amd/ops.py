@@ -543,13 +543,17 @@ def deform_cols(x0: torch.Tensor, x1: torch.Tensor | None, om: torch.Tensor, col
     return cols
 
 
-DEFORM_FUSED_DEFAULT = "0"
-
-
-def deform_fused() -> bool:
-    """Whether the two recurrences run their modulated deformable convolution as one launch (pp_deform_conv) or as
-    pp_deform_cols + 1x1 pp_conv2d (PP_DEFORM_FUSED=1 / 0).  Same results bit for bit either way."""
-    return os.environ.get("PP_DEFORM_FUSED", DEFORM_FUSED_DEFAULT) != "0"
+def deform_fused(h: int, w: int) -> bool:
+    """Whether a recurrence runs its modulated deformable convolution on h x w images as one launch (pp_deform_conv) or as
+    pp_deform_cols + 1x1 pp_conv2d.  Same results bit for bit either way; measured on the MI355X (profiles/r03_deform_fusion.md)
+    the one-launch form wins where the 1x1 convolution would be the in-work-group split-K kernel (small images: flow
+    completion's 45 x 80, 46.9 vs 54.3 us) and loses on large ones (feature propagation's 90 x 160: 378 vs 358 us), so the
+    default follows that kernel's rule (conv_ksplit.hip: at most 160 32-pixel tiles per image).  PP_DEFORM_FUSED=0 / force:
+    never / always."""
+    mode = os.environ.get("PP_DEFORM_FUSED", "1")
+    if mode == "0":
+        return False
+    return mode == "force" or (h * w + 31) // 32 <= 160
 
 
 def _deform_cols_params(x0, x1, om, dg, flow):

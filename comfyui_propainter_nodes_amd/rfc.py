@@ -123,7 +123,7 @@ class FlowCompleter:
         t128 = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
         u128 = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
         om = torch.empty(B, h, w, 432, device=dev, dtype=torch.float32)
-        fused = self.dt == torch.float16 and ops.deform_fused()
+        fused = self.dt == torch.float16 and ops.deform_fused(h, w)
         cols = None if fused else torch.empty(B, h, w, 9 * 256, device=dev, dtype=self.dt)
         aligned = torch.empty(B, h, w, 128, device=dev, dtype=self.dt)
         for name in ("backward_", "forward_"):

@@ -37,16 +37,15 @@ def test_deform_conv_matches_contract(backend):
         assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("tile", ["auto", "16", "32", "ksplit"])
-def test_fused_deform_conv_matches_the_two_kernel_form(backend, pp_knobs, tile):
+@pytest.mark.parametrize("xcd", ["1", "0"])
+def test_fused_deform_conv_matches_the_two_kernel_form(backend, pp_knobs, xcd):
     """pp_deform_conv (sampling feeds the MFMA operand, no column tensor) == pp_deform_cols + 1x1 pp_conv2d: the sampled f16
-    values are the same bit for bit, so the two differ by fp32 summation order only; also against the torchvision contract
-    (oracle/ops.py).  Both call-site shapes (two 128-channel inputs / one input + flow), partial pixel tiles, offsets that leave
-    the image and non-finite offsets, every kernel form (16- / 32-pixel waves, in-work-group split K), f16 and f32 output with
-    a fused epilogue."""
+    values are the same bit for bit, so the two differ by fp32 summation order at most (not at all where the 1x1 convolution
+    is the split-K kernel, whose order pp_deform_conv follows); also against the torchvision contract (oracle/ops.py).
+    Both call-site shapes (two inputs / one input + flow), partial pixel tiles, offsets that leave the image and non-finite
+    offsets, pixel blocks in XCD-contiguous and in launch order, f16 and f32 output with a fused epilogue."""
     dev = backend
-    if tile != "auto":
-        pp_knobs(PP_DEFORM_TILE=tile)
+    pp_knobs(PP_DEFORM_XCD=xcd)
     g = torch.Generator().manual_seed(21)
     for c0, c1, with_flow, odt, (h, w) in ((64, 64, False, torch.float16, (9, 11)), (32, 0, True, torch.float32, (7, 5))):
         n, dg, cout = 2, 4 if c1 == 0 else 16, 128 if c1 else 40
@@ -72,7 +71,7 @@ def test_fused_deform_conv_matches_the_two_kernel_form(backend, pp_knobs, tile):
                               act_param=0.1, epi="add", aux1=res)
         scale = max(1.0, two.float().abs().max().item())
         assert (one.float() - two.float()).abs().max().item() < (2e-3 if odt == torch.float16 else 2e-5) * scale
-        if tile == "auto":   # the default form sums in the order of the 1x1 convolution kernel it replaces
+        if c1:   # 9 x 128 channels: the 1x1 convolution is the split-K kernel, whose summation order pp_deform_conv follows
             assert torch.equal(one, two)
         offr = torch.nan_to_num(off, nan=-1e8, posinf=-1e8, neginf=-1e8)   # non-finite offsets sample nothing
         if with_flow:

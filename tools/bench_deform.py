@@ -1,6 +1,8 @@
 """A/B of the modulated deformable convolution on the MI355X (run via gpurun): the two-launch form (pp_deform_cols + 1x1
-pp_conv2d over the 9*Cin columns) against the one-launch pp_deform_conv in each of its forms (PP_DEFORM_TILE), at the two
-shapes of the pipeline for BASELINE configs[1]:
+pp_conv2d over the 9*Cin columns) against the one-launch pp_deform_conv, pixel blocks in launch order and in XCD-contiguous
+order (PP_DEFORM_XCD), at the two shapes of the pipeline for BASELINE configs[1].  With tools/experiments/deform_conv_forms.patch
+applied the library also has the forms that were measured and not shipped (PP_DEFORM_TILE=16 / 32 / ksplit / ksplit1; without
+the patch the knob is ignored and every row times the shipped form) -- profiles/r03_deform_fusion.md:
 
   featprop  feature propagation of the inpainting generator: nw windows x 90 x 160 pixels, 128 channels, flow added to the offsets
   rfc       flow completion: 2 x 45 x 80 pixels, two 128-channel inputs
@@ -73,22 +75,35 @@ def main():
             ops.deform_cols(x0, x1, om, cols, dg=dg, flow=flow)
             ops.conv2d(spec, [cols], two)
 
-        us_cols = timed(lambda: ops.deform_cols(x0, x1, om, cols, dg=dg, flow=flow), args.reps)
-        us_two = timed(two_launch, args.reps)
-        print(json.dumps({"shape": name, "form": "two launches (pp_deform_cols + pp_conv2d)", "us": round(us_two, 1),
-                          "us_deform_cols_alone": round(us_cols, 1), "gflop": round(gflop, 2), "pixels": n * h * w, "cin": cin}), flush=True)
-        for tile in ("", "16", "32", "ksplit"):
-            if tile:
-                os.environ["PP_DEFORM_TILE"] = tile
-            else:
-                os.environ.pop("PP_DEFORM_TILE", None)
+        def knobs(**kw):
+            for k_, v in kw.items():
+                if v is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v
             lib.reload_options()
-            us = timed(lambda: ops.deform_conv(spec, x0, x1, om, one, dg=dg, flow=flow), args.reps)
-            print(json.dumps({"shape": name, "form": f"pp_deform_conv tile={tile or 'auto'}", "us": round(us, 1),
-                              "speedup_vs_two_launches": round(us_two / us, 2), "bit_identical_to_two_launches": bool(torch.equal(one, two)),
-                              "max_abs_diff": float((one.float() - two.float()).abs().max())}), flush=True)
-        os.environ.pop("PP_DEFORM_TILE", None)
-        lib.reload_options()
+
+        cols_ref = None
+        for xcd in ("0", "1"):
+            knobs(PP_DEFORM_XCD=xcd)
+            us_cols = timed(lambda: ops.deform_cols(x0, x1, om, cols, dg=dg, flow=flow), args.reps)
+            us_two = timed(two_launch, args.reps)
+            same = True if cols_ref is None else bool(torch.equal(cols, cols_ref))
+            cols_ref = cols.clone() if cols_ref is None else cols_ref
+            print(json.dumps({"shape": name, "form": "two launches (pp_deform_cols + pp_conv2d)", "xcd_order": xcd, "us": round(us_two, 1),
+                              "us_deform_cols_alone": round(us_cols, 1), "same_columns_as_launch_order": same,
+                              "gflop": round(gflop, 2), "pixels": n * h * w, "cin": cin}), flush=True)
+            if xcd == "0":
+                us_base = us_two
+            for tile in ("16", "32", "ksplit", "ksplit1"):
+                knobs(PP_DEFORM_TILE=tile)
+                us = timed(lambda: ops.deform_conv(spec, x0, x1, om, one, dg=dg, flow=flow), args.reps)
+                print(json.dumps({"shape": name, "form": f"pp_deform_conv tile={tile}", "xcd_order": xcd, "us": round(us, 1),
+                                  "speedup_vs_two_launches": round(us_base / us, 2),
+                                  "bit_identical_to_two_launches": bool(torch.equal(one, two)),
+                                  "max_abs_diff": float((one.float() - two.float()).abs().max())}), flush=True)
+            knobs(PP_DEFORM_TILE=None)
+        knobs(PP_DEFORM_XCD=None, PP_DEFORM_TILE=None)
 
 
 if __name__ == "__main__":
