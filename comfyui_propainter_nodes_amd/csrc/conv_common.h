@@ -53,6 +53,7 @@ struct ConvK {
   int nchunks;
   const void* pre_add;
   int pre_add_ldc;
+  int tile_order;  // flat-tile kernels: 1 = XCD-contiguous, channel tiles of a pixel tile adjacent (flat_tile_of); 0 = launch order
   const float* weight_f32;  // optional fp32 [tap][chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
 };
 
@@ -120,6 +121,26 @@ __device__ __forceinline__ f4 load_quad(const ET* src, bool vec, int nvalid) {
 template <typename ET>
 __device__ __forceinline__ bool quad_aligned(const ET* ptr, int64_t ldc) {
   return ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(ptr) & (4 * sizeof(ET) - 1)) == 0);
+}
+
+// Work-group -> (pixel tile, channel tile) of the flat-tile kernels (1-D grid of npt * nct work-groups per z).
+// r01-r03 launched a 2-D grid, pixel tiles along x: the nct work-groups that read the SAME pixel tile were npt dispatches
+// apart and on different XCDs, so a GEMM with several channel tiles (the transformer's 512 -> 1536 / 1960 layers: 12 / 16)
+// fetched its activation matrix from the fabric once per channel tile (rocprofv3 FETCH_SIZE of the f16 family: ~2.4x the
+// algorithmic bytes).  Order 1: each XCD owns a contiguous range of the linear tile space with the channel tiles of one pixel
+// tile adjacent (the halo-tile kernels' mapping): they run back to back on one XCD and the pixel tile comes out of its L2.
+__device__ __forceinline__ void flat_tile_of(const ConvK& p, int BC, int& pt, int& ct) {
+  const int nct = (p.Cout + BC - 1) / BC;
+  const int nwg = (int)gridDim.x, id = (int)blockIdx.x;
+  if (p.tile_order) {
+    const int L = xcd_contiguous_block(id, nwg);
+    ct = L % nct;
+    pt = L / nct;
+  } else {
+    const int npt = nwg / nct;
+    pt = id % npt;
+    ct = id / npt;
+  }
 }
 
 // bias + activation(s) + scale + fused epilogue op + channels-last store of 4 consecutive channels

@@ -73,6 +73,7 @@ int convk_from_params(const pp_conv2d_params* p, ConvK* kp, const char* who, boo
   k.aux2 = p->aux2; k.aux2_ldc = (int)p->aux2_ldc; k.aux2_zoff = p->aux2_zoff;
   k.pre_add = p->pre_add; k.pre_add_ldc = (int)p->pre_add_ldc;
   k.weight_f32 = reinterpret_cast<const float*>(p->weight_f32);
+  k.tile_order = options().conv_order;
   if (p->pre_add && p->Z != 1) return fail2(PP_ERR_UNSUPPORTED, who, "pre_add with Z > 1");
   return PP_OK;
 }

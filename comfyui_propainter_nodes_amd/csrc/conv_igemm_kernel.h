@@ -94,8 +94,10 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(const ConvK p)
   const int wc = wave / WP;
   const int wp = wave % WP;
   const int z = (int)blockIdx.z;
-  const int64_t p_base = (int64_t)blockIdx.x * BP;
-  const int c_base = (int)blockIdx.y * BC;
+  int tile_p, tile_c;
+  flat_tile_of(p, BC, tile_p, tile_c);
+  const int64_t p_base = (int64_t)tile_p * BP;
+  const int c_base = tile_c * BC;
 
   const int pc = tid % PPR;   // LDS piece slot inside a tile row (lane-linear: slot index == tid within a pass)
   const int row0 = tid / PPR;
@@ -448,7 +450,7 @@ static int launch_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int NT = WC * WP * 64;
   typedef TileGeom<T, BC, BP, NT> G;
   const size_t smem = (size_t)G::NST * KC * (G::BCP + BP) * G::BK * sizeof(T);
-  dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
+  dim3 grid((unsigned)(((k.M + BP - 1) / BP) * ((k.Cout + BC - 1) / BC)), 1u, (unsigned)Z);
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem), true);
   (void)lds_ok;  // once per instantiation, not per launch
   PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), grid, dim3(NT), smem, stream, k);

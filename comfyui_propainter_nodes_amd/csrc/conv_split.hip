@@ -42,8 +42,10 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
   const int wc = wave / WP;
   const int wp = wave % WP;
   const int z = (int)blockIdx.z;
-  const int64_t p_base = (int64_t)blockIdx.x * BP;
-  const int c_base = (int)blockIdx.y * BC;
+  int tile_p, tile_c;
+  flat_tile_of(p, BC, tile_p, tile_c);
+  const int64_t p_base = (int64_t)tile_p * BP;
+  const int c_base = tile_c * BC;
 
   // slot swizzle of tile row r (depends on r mod 16 only): swz(r) = ((r >> 1) & 7) ^ ((r & 1) << 2).
   //  - fragment reads (16 rows x 4 k-groups per plane): every 16-lane service group of ds_read_b128 hits 16
@@ -289,7 +291,7 @@ static int launch_split_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int NT = WC * WP * 64;
   constexpr int BCP = (BC + NT / 8 - 1) / (NT / 8) * (NT / 8);
   const size_t smem = (size_t)(2 * BP + 3 * BCP) * 128;
-  dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + BC - 1) / BC), (unsigned)Z);
+  dim3 grid((unsigned)(((k.M + BP - 1) / BP) * ((k.Cout + BC - 1) / BC)), 1u, (unsigned)Z);
   static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_split_kernel<OT, WC, WP, TC, TP>), smem), true);
   (void)lds_ok;
   PP_LAUNCH((conv_split_kernel<OT, WC, WP, TC, TP>), grid, dim3(NT), smem, stream, k);

@@ -52,6 +52,8 @@ static void load_options() {
   o.ksplit = tri("PP_CONV_KSPLIT");
   o.direct = tri("PP_CONV_DIRECT");
   o.trace = getenv("PP_CONV_TRACE") != nullptr;
+  o.conv_order = 1;
+  if (const char* e = getenv("PP_CONV_ORDER")) o.conv_order = e[0] != 'l';
   o.tile = 0;
   if (const char* e = getenv("PP_CONV_TILE")) {
     if (e[0] == 'x') o.tile = strcmp(e, "xlforce") == 0 ? 4 : 0;

@@ -6,6 +6,8 @@
 //   PP_CONV_KSPLIT   0 | force   in-work-group split-K kernel off / for every f16 problem with >= 4 chunks
 //   PP_CONV_TILE     large | small | xlforce | tiny | classic   pin one flat-tile family
 //   PP_CONV_DIRECT   0 | force   <= 4-output-channel streaming kernel off / regardless of the image size
+//   PP_CONV_ORDER    launch      flat-tile kernels: work-groups in launch order (pixel tiles first) instead of XCD-contiguous,
+//                                channel-tile-adjacent order (conv_common.h: flat_tile_of)
 //   PP_CONV_TRACE    (set)       print which convolution kernel family ran (debugging aid)
 //   PP_DEFORM_XCD    0           pp_deform_cols / pp_deform_conv walk their pixel blocks in launch order instead of XCD-contiguous order
 #pragma once
@@ -18,6 +20,7 @@ struct Options {
   int tile;     // 0 auto, 1 large, 2 small, 4 xlforce, 5 tiny, 6 classic
   int direct;   // 0 off, 1 auto, 2 force
   int trace;
+  int conv_order;  // 1 (default): XCD-contiguous, channel tiles adjacent; 0: launch order
   int deform_xcd;  // 1 (default): the deformable-sampling kernels walk their pixel blocks in XCD-contiguous order
 };
 const Options& options();

@@ -85,7 +85,8 @@ def _ref_input(x, segC, groups):
                                      pytest.param("hip", "tiny", marks=pytest.mark.gpu),
                                      pytest.param("hip", "halo", marks=pytest.mark.gpu),
                                      pytest.param("hip", "halo_rt", marks=pytest.mark.gpu),
-                                     pytest.param("hip", "ksplit", marks=pytest.mark.gpu)])
+                                     pytest.param("hip", "ksplit", marks=pytest.mark.gpu),
+                                     ("emu", "launch_order"), pytest.param("hip", "launch_order", marks=pytest.mark.gpu)])
 def test_conv2d_matches_torch(be, tile):
     """Every case on both tile families (128-pixel tiles / 32-pixel tiles for small problems).  The tile
     choice is read once per process (PP_CONV_TILE), so each family runs in a fresh interpreter."""
@@ -106,6 +107,8 @@ def test_conv2d_matches_torch(be, tile):
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force")
     if tile == "halo_rt":          # ... with the runtime-tap f16 kernels also where a compile-time-tap form exists (PP_F32X2: flat kernel)
         env.update(PP_CONV_TILE="large", PP_CONV_HALO="force", PP_CONV_HALO_CT="0")
+    if tile == "launch_order":     # ... flat tiles walked in launch order instead of the XCD-contiguous, channel-adjacent default
+        env.update(PP_CONV_TILE="large", PP_CONV_ORDER="launch")
     if tile == "ksplit":           # ... or the in-work-group split-K kernel for every f16 problem with >= 4 chunks
         env.update(PP_CONV_TILE="large", PP_CONV_KSPLIT="force")
     r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
