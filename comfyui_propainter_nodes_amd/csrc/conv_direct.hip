@@ -35,7 +35,9 @@ __global__ void __launch_bounds__(256) conv_small_cout_kernel(const ConvK p, con
   unsigned char* xt = smem + (WG ? (size_t)0 : (size_t)ntaps * nck * COUT * 32 * sizeof(float));
   const float* __restrict__ wg = p.weight_f32;
 
-  const int bid = (int)blockIdx.x;
+  // (16 x 16 tiles in row-major order; XCD-contiguous like the flat tiles: a tile's 2-pixel halo ring is then read by
+  // neighbours on the same XCD instead of being fetched into up to four L2s)
+  const int bid = p.tile_order ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int txi = bid % tiles_x, tyi = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
   const int ty0 = tyi * kDirT, tx0 = txi * kDirT;
 
