@@ -133,9 +133,22 @@ __device__ __forceinline__ void flat_tile_of(const ConvK& p, int BC, int& pt, in
   const int nct = (p.Cout + BC - 1) / BC;
   const int nwg = (int)gridDim.x, id = (int)blockIdx.x;
   if (p.tile_order) {
+    // channel tiles in groups of at most 16 (2 MB of f16 weights at K = 512): a layer with more (the soft-composite's
+    // 512 -> 6272: 49) would cycle through more weights than an L2 holds between two uses of a tile; group by group it
+    // re-reads the pixel tiles once per group instead
+    constexpr int G = 16;
     const int L = xcd_contiguous_block(id, nwg);
-    ct = L % nct;
-    pt = L / nct;
+    const int npt = nwg / nct;
+    const int full = (nct / G) * (npt * G);   // work-groups in whole groups
+    if (L < full) {
+      const int r = L % (npt * G);
+      ct = (L / (npt * G)) * G + r % G;
+      pt = r / G;
+    } else {
+      const int rem = nct % G, r = L - full;
+      ct = (nct / G) * G + r % rem;
+      pt = r / rem;
+    }
   } else {
     const int npt = nwg / nct;
     pt = id % npt;

@@ -194,6 +194,26 @@ def test_f16_conv_with_f32_output(backend, family, pp_knobs):
     assert (out.double().cpu() - ref).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("order", ["default", "launch"])
+def test_many_channel_tiles(backend, order, pp_knobs):
+    """The flat-tile order (conv_common.h: flat_tile_of) on layers with MANY channel tiles: 2 200 and 4 170 output channels
+    = 18 and 33 tiles of 128 (the soft-composite's 512 -> 6272 has 49), i.e. whole groups of 16 plus a remainder group, with a
+    partial last pixel tile; every output element must be written exactly once, in both orders, f16 and PP_F32X2."""
+    if order == "launch":
+        pp_knobs(PP_CONV_ORDER="launch")
+    g = torch.Generator().manual_seed(31)
+    for dt, split, cout, (n, h, w), cin in ((torch.float16, False, 2200, (1, 9, 31), 40), (torch.float32, True, 4170, (2, 5, 13), 12)):
+        x = torch.randn(n, h, w, cin, generator=g).to(dt)
+        wgt = torch.randn(cout, cin, 1, 1, generator=g) * 0.1
+        b = torch.randn(cout, generator=g)
+        spec = ops.make_conv_spec(wgt, b, dt, split=split).to(backend)
+        out = torch.full((n, h, w, cout), float("nan"), device=backend, dtype=dt)
+        ops.conv2d(spec, [x.to(backend)], out)
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), wgt.to(dt).double(), b.double()).permute(0, 2, 3, 1)
+        err = (out.double().cpu() - ref).abs().max().item()   # (NaN if a tile was never written)
+        assert err <= (4e-3 if dt == torch.float16 else 2e-5) * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("halo", ["0", "force"])
 def test_epilogue_from_a_channel(backend, halo, pp_knobs):
     """`epi_from` (ABI v6): RAFT's GRU computes the z and r gates (update.py:41-43) in ONE 256-channel PP_F32X2 convolution
