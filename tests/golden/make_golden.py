@@ -180,6 +180,85 @@ def host_cases():
     print("host_cases written")
 
 
+def schedule_cases(n=400, seed=2024):
+    """Window schedules (neighbour frames + reference frames per window: propainter_inference.py:36-58, 277-299) of `n` seeded
+    random (video_length, neighbor_length, ref_stride, subvideo_length) drawn from the node's INPUT_TYPES ranges, computed with
+    the reference's own get_ref_index and stored as one SHA-1 per combination (plus window / frame counts)."""
+    import hashlib
+    import json
+    import random
+
+    ref_import.load_reference()
+    from reference.propainter_inference import ProPainterConfig, get_ref_index
+
+    rnd = random.Random(seed)
+    keys, digests, counts = [], [], []
+    while len(keys) < n:
+        T = rnd.choice([rnd.randint(2, 40), rnd.randint(2, 400)])
+        nl = rnd.choice([rnd.randint(2, 30), rnd.randint(2, 300)])
+        rs = rnd.choice([rnd.randint(1, 20), rnd.randint(1, 100)])
+        sv = rnd.choice([rnd.randint(1, 100), rnd.randint(1, 300)])
+        cfg = ProPainterConfig(rs, nl, sv, 20, "disable", T, torch.device("cpu"), (640, 360))
+        ns = nl // 2
+        ref_num = sv // rs if T > sv else -1
+        rows = []
+        for f in range(0, T, ns):
+            nb = list(range(max(0, f - ns), min(T, f + ns + 1)))
+            rows.append([nb, get_ref_index(f, nb, cfg, ref_num)])
+        keys.append([T, nl, rs, sv])
+        digests.append(hashlib.sha1(json.dumps(rows).encode()).hexdigest())
+        counts.append([len(rows), sum(len(a) for a, _ in rows), sum(len(b) for _, b in rows)])
+    np.savez_compressed(HERE / "schedule_cases.npz", keys=np.array(keys), digests=np.array(digests), counts=np.array(counts))
+    print("schedule_cases written:", n, "combinations,", sum(1 for k in keys if k[0] > k[3]), "in local-reference mode")
+
+
+def chunk_plan_cases(n=80, seed=7):
+    """Sub-video plans of flow completion (propainter_inference.py:115-144: chunks of subvideo_length flows, 5-frame halos) and
+    image propagation (:172-212: chunks of min(100, subvideo_length) frames, 10-frame halos) for `n` seeded random
+    (video_length, subvideo_length), recorded by running the REFERENCE's functions with stand-in models whose output encodes
+    where it was computed: frame g of the result = 1000 * (first frame of the chunk it came from) + its index in that chunk."""
+    import random
+    from types import SimpleNamespace
+
+    ref_import.load_reference()
+    from reference.propainter_inference import ProPainterConfig, complete_flow, image_propagation
+
+    class FakeRFC:
+        def forward_bidirect_flow(self, flows, masks):
+            t = flows[0].shape[1]
+            tag = flows[0][:, :1, :1] * 1000 + torch.arange(t, dtype=torch.float32).view(1, t, 1, 1, 1)
+            return (tag.expand(-1, -1, 2, -1, -1).clone(), tag.expand(-1, -1, 2, -1, -1).clone() + 0.5), None
+
+        def combine_flow(self, flows, pred, masks):
+            return pred
+
+    class FakeGen:
+        def img_propagation(self, masked_frames, flows, masks, mode):
+            t = masks.shape[1]
+            first = flows[0][0, 0, 0, 0, 0]                    # the flows carry their global index (a chunk has >= 2 frames)
+            tag = first * 1000 + torch.arange(t, dtype=torch.float32)
+            return tag.view(1, t, 1, 1, 1).expand(1, t, 3, 1, 1).clone(), (tag % 200).view(1, t, 1, 1, 1).clone()
+
+    rnd = random.Random(seed)
+    keys, flow_plans, img_plans, img_masks = [], [], [], []
+    while len(keys) < n:
+        T = rnd.choice([rnd.randint(2, 30), rnd.randint(2, 260)])
+        sv = rnd.choice([rnd.randint(1, 12), rnd.randint(1, 130)])
+        nf = T - 1
+        idx = torch.arange(nf, dtype=torch.float32).view(1, nf, 1, 1, 1).expand(1, nf, 2, 1, 1)
+        pf = complete_flow(FakeRFC(), (idx.clone(), idx.clone()), torch.zeros(1, T, 1, 1, 1), sv)
+        cfg = ProPainterConfig(10, 10, sv, 20, "disable", T, torch.device("cpu"), (1, 1))
+        # masks_dilated = 1 everywhere: updated = frames * (1 - m) + prop * m = prop
+        uf, um = image_propagation(FakeGen(), torch.zeros(1, T, 3, 1, 1), torch.ones(1, T, 1, 1, 1), (idx.clone(), idx.clone()), cfg)
+        keys.append([T, sv])
+        flow_plans.append(pf[0][0, :, 0, 0, 0].numpy().astype(np.int64))
+        img_plans.append(uf[0, :, 0, 0, 0].numpy().astype(np.int64))
+        img_masks.append(um[0, :, 0, 0, 0].numpy().astype(np.int64))
+    np.savez_compressed(HERE / "chunk_plans.npz", keys=np.array(keys), flow=np.concatenate(flow_plans), img=np.concatenate(img_plans),
+                        img_mask=np.concatenate(img_masks))
+    print("chunk_plans written:", n, "combinations,", sum(1 for T, sv in keys if T - 1 > sv), "with chunked flow completion")
+
+
 def _rel(a, b):
     return rel_err(a, b)
 
@@ -343,6 +422,9 @@ def main():
     torch.set_num_threads(8)
     if args.case in ("all", "host"):
         host_cases()
+    if args.case in ("all", "schedules"):
+        schedule_cases()
+        chunk_plan_cases()
     for name, kw in CASES.items():
         if args.case in ("all", name):
             run_case(name, save=not args.no_save, **kw)

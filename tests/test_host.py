@@ -112,6 +112,52 @@ def test_window_schedules_match_reference(host_cases):
         assert got == ref, key
 
 
+def test_window_schedules_match_reference_on_random_parameters():
+    """400 seeded random (video_length, neighbor_length, ref_stride, subvideo_length) from the node's parameter ranges -- global
+    and local reference mode, odd strides, windows longer than the clip, 1-frame sub-videos: the schedule equals the one the
+    reference's own get_ref_index loop produced (tests/golden/make_golden.py: schedule_cases, one SHA-1 per combination)."""
+    import hashlib
+    import json
+
+    g = np.load(Path(__file__).parent / "golden" / "schedule_cases.npz")
+    for (T, nl, rs, sv), want, cnt in zip(g["keys"].tolist(), g["digests"].tolist(), g["counts"].tolist()):
+        cfg = pipeline.ProPainterConfig(rs, nl, sv, 20, "enable", T, torch.device("cuda"), (640, 360))
+        rows = [[nb, refs] for nb, refs in pipeline.window_schedule(cfg)]
+        assert [len(rows), sum(len(a) for a, _ in rows), sum(len(b) for _, b in rows)] == cnt, (T, nl, rs, sv)
+        assert hashlib.sha1(json.dumps(rows).encode()).hexdigest() == want, (T, nl, rs, sv)
+
+
+def test_subvideo_plans_match_reference(monkeypatch):
+    """Which sub-video every completed flow / propagated frame is computed in, and at which position of it (flow completion:
+    chunks of subvideo_length flows with 5-frame halos; image propagation: chunks of min(100, subvideo_length) frames with
+    10-frame halos), for 80 seeded random (video_length, subvideo_length): equal to what the REFERENCE's complete_flow /
+    image_propagation did with stand-in models that tag their output (tests/golden/make_golden.py: chunk_plan_cases)."""
+    g = np.load(Path(__file__).parent / "golden" / "chunk_plans.npz")
+
+    def fake_rfc(flows, masks):              # [2,n,1,1,2] -> frame j of the chunk = 1000 * (first flow of the chunk) + j
+        n = flows.shape[1]
+        return (flows[:1, :1] * 1000 + torch.arange(n, dtype=torch.float32).view(1, n, 1, 1, 1)).expand(2, n, 1, 1, 2).clone()
+
+    def fake_imgprop(frames, masks_u8, flows):
+        t = frames.shape[0]
+        tag = flows[0, 0, 0, 0, 0] * 1000 + torch.arange(t, dtype=torch.float32)
+        return tag.view(t, 1, 1, 1).expand(t, 1, 1, 3).clone(), (tag % 200).to(torch.uint8).view(t, 1, 1)
+
+    monkeypatch.setattr(pipeline.imgprop, "image_propagation", fake_imgprop)
+    of = oi = 0
+    for T, sv in g["keys"].tolist():
+        nf = T - 1
+        idx = torch.arange(nf, dtype=torch.float32).view(1, nf, 1, 1, 1).expand(2, nf, 1, 1, 2).contiguous()
+        got = pipeline.complete_flow(fake_rfc, idx, torch.zeros(T, 1, 1, dtype=torch.uint8), sv)[0, :, 0, 0, 0]
+        assert got.long().tolist() == g["flow"][of:of + nf].tolist(), (T, sv)
+        cfg = pipeline.ProPainterConfig(10, 10, sv, 20, "enable", T, "cpu", (1, 1))
+        prop, upd = pipeline.image_propagation(torch.zeros(T, 1, 1, 3), torch.ones(T, 1, 1, dtype=torch.uint8), idx, cfg)
+        assert prop[:, 0, 0, 0].long().tolist() == g["img"][oi:oi + T].tolist(), (T, sv)
+        assert upd[:, 0, 0].long().tolist() == g["img_mask"][oi:oi + T].tolist(), (T, sv)
+        of += nf
+        oi += T
+
+
 def test_survey_window_counts():
     """SURVEY.md section 3 table (computed there with the reference's get_ref_index)."""
     for (T, nl, rs, sv), (nwin, sum_lt, sum_t) in {(16, 10, 10, 80): (4, 34, 37), (80, 10, 10, 80): (16, 170, 275),
