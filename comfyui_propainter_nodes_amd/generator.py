@@ -202,7 +202,10 @@ class InpaintGeneratorMI355:
         """nw windows starting at clip frames g0s, each with lt local frames -> f16 [lt, nw, h, w, 128].  The sweep is
         2 x lt steps of ~10 small dependent launches: captured once per (window set, clip shape) into a hipGraph and
         replayed on static copies of the per-clip tensors (graphs.py)."""
-        return self._graphs.run(("featprop", tuple(g0s), lt), lambda *t: self._featprop_eager(g0s, lt, *t),
+        # (the key carries what the captured launches depend on besides the input shapes: the window set and the form of
+        # the deformable convolution, an environment knob)
+        fused = ops.deform_fused(st.enc.shape[1], st.enc.shape[2])
+        return self._graphs.run(("featprop", tuple(g0s), lt, fused), lambda *t: self._featprop_eager(g0s, lt, *t),
                                 st.enc, st.maskpair, st.flow_f, st.flow_b, st.aux_b, st.aux_f)
 
     def _featprop_eager(self, g0s: list[int], lt: int, enc, maskpair, flow_f, flow_b, aux_b, aux_f) -> torch.Tensor:

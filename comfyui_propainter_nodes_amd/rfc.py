@@ -112,7 +112,7 @@ class FlowCompleter:
         replayed (graphs.py); the result lives in the graph's static buffer until the next call with this shape."""
         if not capture:
             return self._propagate_eager(mid)
-        return self._graphs.run(("rfc_propagate",), self._propagate_eager, mid)
+        return self._graphs.run(("rfc_propagate", ops.deform_fused(mid.shape[2], mid.shape[3])), self._propagate_eager, mid)
 
     def _propagate_eager(self, mid: torch.Tensor) -> torch.Tensor:
         """BidirectionalPropagation.forward (:77-143) on mid [T,2,h,w,128] -> [T,2,h,w,128]."""
