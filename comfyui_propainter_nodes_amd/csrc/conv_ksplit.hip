@@ -36,7 +36,11 @@ __global__ void __launch_bounds__(kKS * 256) conv_ksplit_kernel(const ConvK p) {
   const int wave = tid >> 6;               // wave inside the group = its channel block
   T* smem = smem_all + grp * NST * STAGE;
   const int z = (int)blockIdx.z;
-  const int64_t p_base = (int64_t)blockIdx.x * BP;
+  // 32-pixel tiles in XCD-contiguous order (r03; Cout <= 128 here, gridDim.y == 1): dealt round robin, each of the 8 XCDs
+  // pulled the whole 2-6 MB input of such a layer through its own L2 -- r03_pmc_fetch_size.json: 18.8 MB read per launch
+  // where inputs + weights average ~6.5 MB
+  const int ptile = (p.tile_order && gridDim.y == 1) ? xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int64_t p_base = (int64_t)ptile * BP;
   const int c_base = (int)blockIdx.y * BC;
 
   const int pc = tid % PPR;
