@@ -12,6 +12,11 @@ from comfyui_propainter_nodes_amd import nodes, synth
 
 GOLD = Path(__file__).parent / "golden"
 
+# the corners of the node's parameter ranges (tests/golden/make_golden.py: EDGE_CASES)
+EDGE = ["edge_T2_min", "edge_T3_odd_nl_no_refs", "edge_T7_nl300", "edge_T6_sv1", "edge_T6_sv2", "edge_T9_sv8", "edge_T8_sv8",
+        "edge_T5_ragged", "edge_T5_nl5", "edge_T4_no_mask", "edge_T4_full_mask", "edge_T4_dil100", "edge_T4_outpaint_h",
+        "edge_T4_outpaint_both", "edge_T4_outpaint_none"]
+
 
 def psnr(a, b, peak=255.0):
     if a.size == 0:

@@ -18,11 +18,8 @@ import pytest
 import torch
 
 from comfyui_propainter_nodes_amd import nodes, pipeline
-from node_case import check_node_case
+from node_case import EDGE, check_node_case
 
-EDGE = ["edge_T2_min", "edge_T3_odd_nl_no_refs", "edge_T7_nl300", "edge_T6_sv1", "edge_T6_sv2", "edge_T9_sv8", "edge_T8_sv8",
-        "edge_T5_ragged", "edge_T5_nl5", "edge_T4_no_mask", "edge_T4_full_mask", "edge_T4_dil100", "edge_T4_outpaint_h",
-        "edge_T4_outpaint_both", "edge_T4_outpaint_none"]
 _EMU = os.environ.get("PP_EDGE_EMU", "")
 EMULATED = EDGE if _EMU == "all" else [c for c in _EMU.split(",") if c]
 
