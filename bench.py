@@ -87,7 +87,7 @@ def reference_timings():
     timed when the fixtures were minted in the build container (tests/golden/make_golden.py; /root/reference does not exist
     on the GPU box, so it cannot be re-timed here)."""
     out = []
-    for name in ("cfg2_80f_node", "cfg2_24f_node", "cfg4_100f_node"):
+    for name in ("cfg2_80f_node", "cfg2_24f_node", "cfg4_100f_node", "cfg3_80f_node", "cfg5_90f_node", "cfg4_170f_node"):
         f = ROOT / "tests" / "golden" / f"{name}.npz"
         if f.exists():
             g = np.load(f)
@@ -108,12 +108,19 @@ def cpu_baseline(sds, models, dev, n_frames=12):
         sweep[th] = round(_oracle_seconds(sds, 3, th)[0], 2)
     best = min(sweep, key=sweep.get)
     dt, ref, otr, inputs = _oracle_seconds(sds, n_frames, best)
+    runs = reference_timings()
+    ref80 = next((r for r in runs if r["fixture"] == "cfg2_80f_node"), runs[0] if runs else None)
     base = {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": best, "host_cores": host, "kind": "port",
+            # the reference ITSELF on this workload (its node method, CPU fp32): timed once in the build container when the
+            # fixture was minted -- /root/reference does not exist on the GPU box, so `value` (timed here, now) is the oracle port
+            "reference_value": ref80["frames_per_s"] if ref80 else None, "reference_cores": ref80["threads"] if ref80 else None,
+            "reference_sample": (f"{ref80['frames']}-frame 640x360 clip through the reference's node method, {ref80['seconds']} s "
+                                 f"(tests/golden/{ref80['fixture']}.npz: ref_seconds)") if ref80 else None,
             "sample": f"{n_frames}-frame 640x360 clip, raft_iter {CFG['raft_iter']}, fp32, oracle/ (CPU restatement of the "
                       f"reference), {dt:.1f} s",
             "thread_sweep_s_for_3_frames": sweep,
             "reference_itself": {"what": "the reference's own node method on CPU fp32, timed in the build container when the "
-                                         "fixtures were minted (8 threads)", "runs": reference_timings()}}
+                                         "fixtures were minted (8 threads)", "runs": runs}}
     return base, (ref, otr, inputs)
 
 
@@ -342,6 +349,13 @@ def main():
                     "flops_per_launch": d["flops"] / d["n"], "share_of_step_ms": round(d["ms"], 1),
                     "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 1), "launches": v["n"]}
                               for k, v in prof.items() if k != dom and k not in ("attention", "corr_lookup")}}
+        # end-to-end: every MFMA flop of the step priced at its family's nominal peak (PP_F32X2 at 2.5 PF / 3 products), against
+        # the wall time of the timed step (the whole step as a fraction of the blended MFMA roofline)
+        ideal_ms = sum(v["flops"] / (PEAK_TFLOPS.get(k, PEAK_TFLOPS["f16"]) * 1e12) * 1e3 for k, v in prof.items()
+                       if k != "corr_lookup" and v["flops"] > 0)
+        roofline["e2e_tflop_per_step"] = {k: round(v["flops"] / 1e12, 2) for k, v in prof.items() if v["flops"] > 0}
+        roofline["e2e_ideal_ms"] = round(ideal_ms, 1)
+        roofline["e2e_frac"] = round(ideal_ms / ms_per_step, 4)
         if "attention" in prof:   # north_star: MFMA utilisation of the attention GEMMs
             v = prof["attention"]
             tf = v["flops"] / (v["ms"] * 1e-3) / 1e12

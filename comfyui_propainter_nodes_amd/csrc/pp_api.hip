@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 namespace pp {
 
 static thread_local char g_err[512] = {0};
@@ -37,8 +40,11 @@ void pp_allow_big_lds(const void* func, size_t bytes) {
 #endif
 }
 
-static Options g_options;
-static bool g_options_loaded = false;
+// The knobs are read ONCE (first use, under std::call_once: two host threads may issue their first launch concurrently) and
+// again only by pp_reload_options().  A reload publishes a fresh immutable snapshot; readers keep whichever snapshot they saw.
+static std::atomic<const Options*> g_options{nullptr};
+static std::once_flag g_options_once;
+static std::mutex g_options_mutex;
 
 static int tri(const char* name) {  // unset -> 1 (auto), "0..." -> 0, "f..." -> 2
   const char* e = getenv(name);
@@ -63,13 +69,13 @@ static void load_options() {
   }
   o.deform_xcd = 1;
   if (const char* e = getenv("PP_DEFORM_XCD")) o.deform_xcd = e[0] != '0';
-  g_options = o;
-  g_options_loaded = true;
+  std::lock_guard<std::mutex> lock(g_options_mutex);
+  g_options.store(new Options(o), std::memory_order_release);  // old snapshots stay valid for readers (a few bytes per reload)
 }
 
 const Options& options() {
-  if (!g_options_loaded) load_options();
-  return g_options;
+  std::call_once(g_options_once, load_options);
+  return *g_options.load(std::memory_order_acquire);
 }
 
 }  // namespace pp

@@ -1,8 +1,10 @@
-// pp_options.h -- the library's tuning / test knobs, read from the environment ONCE (first use) and again only when
-// pp_reload_options() is called (tests that switch a knob inside one process).  Every knob pins a kernel family for
+// pp_options.h -- the library's tuning / test knobs, read from the environment ONCE (first use, thread-safe) and FROZEN from then
+// on: a later os.environ change is ignored until pp_reload_options() is called (lib.reload_options(); tests and tools that switch a
+// knob inside one process).  Every knob pins a kernel family for
 // tests or A/B runs; none changes results beyond the summation order of the selected kernel.
 //   PP_CONV_HALO     0 | force   halo-tile kernels off / for every eligible geometry regardless of the problem size
-//   PP_CONV_HALO_CT  0           runtime-tap halo kernels instead of the compile-time-tap ones
+//   PP_CONV_HALO_CT  0           f16: the runtime-tap halo kernel everywhere; PP_F32X2: the flat kernel instead of the
+//                                compile-time-tap halo kernels (the runtime-tap PP_F32X2 halo kernel lives in tools/experiments)
 //   PP_CONV_KSPLIT   0 | force   in-work-group split-K kernel off / for every f16 problem with >= 4 chunks
 //   PP_CONV_TILE     large | small | xlforce | tiny | classic   pin one flat-tile family
 //   PP_CONV_DIRECT   0 | force   <= 4-output-channel streaming kernel off / regardless of the image size

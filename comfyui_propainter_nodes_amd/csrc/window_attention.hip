@@ -3,7 +3,8 @@
 //   window_attention_f16_kernel      f16 storage (the node's fp16 "enable"): K / V tiles by LDS-DMA, double-buffered,
 //                                    32x32x16 MFMAs, V consumed through the transposing LDS read;
 //   window_attention_generic_kernel  fp32 storage (fp16 "disable"): register-staged tiles converted to f16 MFMA operands,
-//                                    16x16x32 MFMAs (the round-1/2 kernel).
+//                                    16x16x32 MFMAs (the round-1/2 kernel); also f16 storage beyond the f16 kernel's
+//                                    limits (> 1024 key frames, frames of >= 2^30 elements).
 #include "attn_device.h"
 #include "pp_host.h"
 
@@ -263,7 +264,8 @@ __global__ void __launch_bounds__(256) window_attention_generic_kernel(const Att
 //             holds, for query q = lane & 31, the scores of keys (r&3) + 8*(r>>2) + 4*h, r = 0..15, of the tile;
 //   softmax   online, lane-local over its 16 scores + one v_permlane32_swap for the row maximum; the row sum stays
 //             split over the two half-waves until the end; O / l are rescaled only when some row maximum of the wave
-//             moved (wave-uniform branch, exact);
+//             grew by more than 2^kAtDefer = 2^8 since the last rescale (wave-uniform branch; until then the tile's
+//             probabilities are taken against the OLD reference maximum, at most 2^8 too large: exact in f32/f16 range);
 //   O^T      += V^T . P^T: B = the lane's own probabilities (registers 8m..8m+7 of S as f16: keys 16m+4h+{0..3} and
 //             16m+8+4h+{0..3}), A = two ds_read_b64_tr_b16 of the row-major V tile in the same key order -- the
 //             probabilities never leave registers and V is never transposed in memory.
@@ -771,9 +773,10 @@ extern "C" int32_t pp_window_attention(void* stream, const pp_window_attention_p
   if (p->Hp % kWinH || p->Wp % kWinW) return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: grid not padded to 5x9 windows");
   if (p->t < 1 || p->nt < 1 || p->t > 65535) return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: bad t / nt");
   if (p->dtype == PP_F16) {
-    // 32-bit element offsets inside a frame, the t_ind table in LDS
-    if (p->nt > kAtMaxNt || p->Hp * p->Wp * (3 * kDim) >= (int64_t)1 << 30)
-      return pp_fail(PP_ERR_UNSUPPORTED, "pp_window_attention: more than 1024 key frames or a frame beyond 2^30 elements");
+    // the f16 kernel keeps 32-bit element offsets inside a frame and the t_ind table in LDS; beyond those limits the
+    // generic kernel (64-bit addressing, no table) serves f16 storage as it did until r02
+    if (p->nt > kAtMaxNt || (int64_t)p->Hp * p->Wp * (3 * kDim) >= (int64_t)1 << 30)
+      return launch_window_attention_generic<half_t>(stream, p);
     return launch_window_attention_f16(stream, p);
   }
   if (p->dtype == PP_F32) return launch_window_attention_generic<float>(stream, p);

@@ -66,12 +66,16 @@ class GraphCache:
             # tensors, allocator growth) must not happen inside the capture
             s = torch.cuda.Stream(inputs[0].device)
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                fn(*static_in)
-            torch.cuda.current_stream().wait_stream(s)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = fn(*static_in)
+            ops.PIN_DEVICE_INTS += 1      # index tensors requested from here on are baked into the graph: never evicted
+            try:
+                with torch.cuda.stream(s):
+                    fn(*static_in)
+                torch.cuda.current_stream().wait_stream(s)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = fn(*static_in)
+            finally:
+                ops.PIN_DEVICE_INTS -= 1
             e = _Entry(g, static_in, out)
             self._entries[key] = e
             while len(self._entries) > _MAX_GRAPHS:

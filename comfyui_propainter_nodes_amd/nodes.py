@@ -381,7 +381,10 @@ class ProPainterOutpaint:
         print(f"\nProcessing  {config.video_length} frames...")
         # the border masks are a function of the canvas geometry alone: the masked-window set of the transformer is cached
         # per geometry across node executions (image_utils.py:200-252 recomputes the planes per call)
-        geometry = ("outpaint", tuple(config.process_size), tuple(input_size), mask_dilates, float(width_scale), float(height_scale))
+        # (canvas size, resized frame size, input size, scales: the resized frame size decides where the frame sits on the canvas --
+        # two calls can share every other entry and still have different border planes; mask_dilates does not enter them)
+        geometry = ("outpaint", tuple(config.process_size), tuple(image_config.process_size), tuple(input_size),
+                    float(width_scale), float(height_scale))
         output_frames, output_masks, _ = _run(models, config, fr_u8, fr_f32, fm, md, tm, static_masks=geometry)
         output_width, output_height = config.process_size
         return output_frames, output_masks, output_width, output_height

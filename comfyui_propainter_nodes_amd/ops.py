@@ -7,6 +7,8 @@ channels-last `[N, H, W, C]`; a view whose last-dim slice is narrower than its p
 from __future__ import annotations
 
 import ctypes
+import functools
+from collections import OrderedDict
 from dataclasses import dataclass
 
 import os
@@ -65,19 +67,34 @@ class ConvProfile:
 CONV_PROFILE: ConvProfile | None = None
 
 
-_INT_CACHE: dict = {}
+_INT_CACHE: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()   # bounded LRU: lists no captured graph refers to
+_INT_PINNED: dict = {}                                            # lists handed out while a hipGraph was being captured
+_INT_CACHE_MAX = 4096
+PIN_DEVICE_INTS = 0   # > 0 while graphs.GraphCache warms up / captures a sweep (its replays read these addresses)
 
 
 def device_ints(values, device, dtype: torch.dtype = torch.int64) -> torch.Tensor:
     """A small integer index tensor on the device, cached by value (window / reference frame ids recur every clip,
-    so the steady state issues no pageable H2D copies for them)."""
+    so the steady state issues no pageable H2D copies for them).  Lists requested while a hipGraph is being captured
+    (graphs.py bakes their addresses into the graph) are pinned for the life of the process -- one set per captured
+    problem shape; everything else lives in an LRU of `_INT_CACHE_MAX` entries, so a long-lived ComfyUI process does not
+    grow without bound."""
     key = (tuple(values), str(device), dtype)
+    t = _INT_PINNED.get(key)
+    if t is not None:
+        return t
     t = _INT_CACHE.get(key)
     if t is None:
-        # never evicted: captured hipGraphs (graphs.py) bake in the addresses of the tensors handed out here, so a tensor
-        # must stay alive as long as any graph may replay it.  Entries are a few dozen bytes (window / frame id lists);
-        # 10^5 distinct lists are a few MB.
-        t = _INT_CACHE[key] = torch.tensor(list(values), dtype=dtype, device=device)
+        t = torch.tensor(list(values), dtype=dtype, device=device)
+    else:
+        _INT_CACHE.move_to_end(key)
+    if PIN_DEVICE_INTS > 0:
+        _INT_CACHE.pop(key, None)
+        _INT_PINNED[key] = t
+        return t
+    _INT_CACHE[key] = t
+    while len(_INT_CACHE) > _INT_CACHE_MAX:
+        _INT_CACHE.popitem(last=False)
     return t
 
 
@@ -453,8 +470,8 @@ def tiled_pitch(h: int, w: int) -> int:
     return -(-h // 4) * -(-w // 8) * 32
 
 
-def tiled_order(h: int, w: int) -> list[int]:
-    """Source pixel (y*w + x) of every position of a tiled h x w plane; the zero padding is index h*w."""
+@functools.lru_cache(maxsize=64)
+def _tiled_order(h: int, w: int) -> tuple:
     th, tw = -(-h // 4), -(-w // 8)
     out = []
     for ty in range(th):
@@ -463,7 +480,25 @@ def tiled_order(h: int, w: int) -> list[int]:
                 for c in range(8):
                     y, x = 4 * ty + r, 8 * tx + c
                     out.append(y * w + x if y < h and x < w else h * w)
-    return out
+    return tuple(out)
+
+
+def tiled_order(h: int, w: int) -> list[int]:
+    """Source pixel (y*w + x) of every position of a tiled h x w plane; the zero padding is index h*w."""
+    return list(_tiled_order(h, w))
+
+
+_TILED_INDEX: dict = {}
+
+
+def tiled_order_index(h: int, w: int, device) -> torch.Tensor:
+    """tiled_order(h, w) as an int64 device tensor, built once per (h, w, device) (RAFT asks for it per chunk: the list is
+    ~15k integers at 90x160)."""
+    key = (h, w, str(device))
+    t = _TILED_INDEX.get(key)
+    if t is None:
+        t = _TILED_INDEX[key] = torch.tensor(_tiled_order(h, w), dtype=torch.int64, device=device)
+    return t
 
 
 def avgpool2x2(x: torch.Tensor, out: torch.Tensor, hw: tuple[int, int] | None = None, in_tiled: bool = False,

@@ -188,7 +188,7 @@ class RaftFlow:
         # (zero rows for the tile padding: 45 -> 48 rows at 640x360); the small levels 2 and 3 stay row-major.
         pitch0 = ops.tiled_pitch(h, w)
         f2z = torch.cat([f2, torch.zeros(P, 1, 256, device=dev)], 1)
-        f2t = f2z.index_select(1, ops.device_ints(ops.tiled_order(h, w), dev))
+        f2t = f2z.index_select(1, ops.tiled_order_index(h, w, dev))
         vol = torch.empty(P, 1, hw, pitch0, device=dev)
         ops.batched_gemm_nt(f1.view(P, 1, hw, 256), f2t, vol, scale=1.0 / 16.0, split=ops.f32_split_enabled())
         pyr = [(vol.view(P, hw, pitch0), h, w, True)]

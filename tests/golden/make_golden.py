@@ -375,6 +375,19 @@ NODE_CASES = {
     # per-frame (moving) MASK input, mask.shape[0] == T: one dilation per mask frame (image_utils.py:142-175)
     "mov_20f_node": dict(kind="inpaint", T=20, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
                          ref_stride=10, subvideo_length=80, mask_kind="moving"),
+    # --- r04: the BASELINE configurations at their stated length (VERDICT r03 row h) ---------------------------------------------
+    # configs[2] IN FULL: 80-frame outpaint 640x360 -> 768x360 canvas (width_scale 1.2, 64-px border masks)
+    "cfg3_80f_node": dict(kind="outpaint", T=80, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                          ref_stride=10, subvideo_length=80, flow_stride=8),
+    # configs[4]'s size AND mode: 1280x720, neighbor_length 20, ref_stride 10, raft_iter 20 on 90 frames > subvideo_length 80:
+    # local reference frames (ref_num 8), RAFT in short clips of 4 (propainter_inference.py:65-72), two flow-completion and
+    # two image-propagation sub-videos, 60x107 -> 60x108 token grid, 21-frame windows
+    "cfg5_90f_node": dict(kind="inpaint", T=90, H=720, W=1280, width=1280, height=720, raft_iter=20, neighbor_length=20,
+                          ref_stride=10, subvideo_length=80, flow_stride=16),
+    # an INTERIOR sub-video at real size: 170 frames of 640x360 = flow-completion sub-videos [0,80) [80,160) [160,169) and
+    # image-propagation sub-videos [0,80) [80,160) [160,170): the middle one has halos on BOTH sides (propainter_inference.py:115-144, 172-212)
+    "cfg4_170f_node": dict(kind="inpaint", T=170, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                           ref_stride=10, subvideo_length=80, flow_stride=8),
 }
 
 
