@@ -432,6 +432,8 @@ int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // ... and its halo-tile form for stride-1 multi-tap convolutions (conv_halo.hip); returns 1 when not eligible
 int launch_halo_split(void* stream, const ConvK& k, int Z);
 int launch_halo_f16(void* stream, const ConvK& k, int Z, bool out_f16);
+// conv_gemm_f16.hip: 1x1 / stride-1 / unpadded single-segment f16 layers (plain GEMMs); returns 1 when not eligible
+int launch_gemm_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // conv_direct.hip: at most 4 output channels, streaming fp32-FMA kernel; returns 1 when not eligible
 int launch_direct_small_cout(void* stream, const ConvK& k, int Z, int dtype, bool out_f16);
 

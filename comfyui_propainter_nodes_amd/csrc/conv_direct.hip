@@ -177,8 +177,7 @@ static int launch_direct_t(void* stream, const ConvK& k, int wmode) {
   dim3 grid((unsigned)blocks), block(256);
 #define PP_DIRECT_LAUNCH(C, W)                                                                                              \
   do {                                                                                                                      \
-    static const bool ok_ = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_small_cout_kernel<T, OT, C, W>), 150 * 1024), true); \
-    (void)ok_;                                                                                                              \
+    PP_ALLOW_BIG_LDS((&conv_small_cout_kernel<T, OT, C, W>), 150 * 1024);                                                     \
     PP_LAUNCH((conv_small_cout_kernel<T, OT, C, W>), grid, block, smem, stream, k, tiles_x, tiles_y, wmode);                \
   } while (0)
   if (cmax == 2) {

@@ -312,8 +312,7 @@ static int launch_halo_ct_cfg(void* stream, const ConvK& k, int Z, HaloGeom g) {
   const size_t smem = (size_t)XPASS * (NT / 4) * 160 + (size_t)3 * BCP * 128;
   g.nct = (k.Cout + BC - 1) / BC;
   dim3 grid((unsigned)(g.ntiles * g.nct), 1u, (unsigned)Z);
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), smem), true);
-  (void)lds_ok;
+  PP_ALLOW_BIG_LDS((&conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), smem);
   PP_LAUNCH((conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), grid, dim3(NT), smem, stream, k, g);
   return pp_check_launch("pp_conv2d");
 }

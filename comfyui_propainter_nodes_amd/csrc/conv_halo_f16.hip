@@ -410,8 +410,7 @@ static int launch_halo_f16_ct_cfg(void* stream, const ConvK& k, int Z, HaloGeom 
   const size_t smem = (size_t)(2 * XPASS * RPP + 2 * 3 * BCP) * 64;
   g.nct = (k.Cout + BC - 1) / BC;
   dim3 grid((unsigned)(g.ntiles * g.nct), 1u, (unsigned)Z);
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_halo_f16_ct_kernel<OT, WC, WP, TC, TP>), smem), true);
-  (void)lds_ok;
+  PP_ALLOW_BIG_LDS((&conv_halo_f16_ct_kernel<OT, WC, WP, TC, TP>), smem);
   PP_LAUNCH((conv_halo_f16_ct_kernel<OT, WC, WP, TC, TP>), grid, dim3(NT), smem, stream, k, g);
   return pp_check_launch("pp_conv2d");
 }
@@ -425,8 +424,7 @@ static int launch_halo_f16_cfg(void* stream, const ConvK& k, int Z, HaloGeom g) 
   const size_t smem = (size_t)(2 * XPASS * RPP + 3 * BCP) * 64;
   g.nct = (k.Cout + BC - 1) / BC;
   dim3 grid((unsigned)(g.ntiles * g.nct), 1u, (unsigned)Z);
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_halo_f16_kernel<OT, WC, WP, TC, TP, XPASS>), smem), true);
-  (void)lds_ok;
+  PP_ALLOW_BIG_LDS((&conv_halo_f16_kernel<OT, WC, WP, TC, TP, XPASS>), smem);
   PP_LAUNCH((conv_halo_f16_kernel<OT, WC, WP, TC, TP, XPASS>), grid, dim3(NT), smem, stream, k, g);
   return pp_check_launch("pp_conv2d");
 }

@@ -95,6 +95,8 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
     if (rc != 1) return rc;
     const int rh = launch_halo_f16(stream, k, Z, p->out_dtype == PP_F16);  // stride-1 multi-tap: pixel tile + halo staged once per chunk
     if (rh != 1) return rh;
+    const int rg = launch_gemm_f16(stream, k, Z, p->out_dtype == PP_F16);  // 1x1 / stride 1 / no padding: plain GEMM
+    if (rg != 1) return rg;
     return p->out_dtype == PP_F16 ? launch_igemm_hh(stream, k, Z) : launch_igemm_hf(stream, k, Z);
   }
   if (p->dtype == PP_F32X2) {

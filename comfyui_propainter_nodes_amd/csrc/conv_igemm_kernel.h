@@ -451,8 +451,7 @@ static int launch_cfg(void* stream, const ConvK& k, int Z) {
   typedef TileGeom<T, BC, BP, NT> G;
   const size_t smem = (size_t)G::NST * KC * (G::BCP + BP) * G::BK * sizeof(T);
   dim3 grid((unsigned)(((k.M + BP - 1) / BP) * ((k.Cout + BC - 1) / BC)), 1u, (unsigned)Z);
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem), true);
-  (void)lds_ok;  // once per instantiation, not per launch
+  PP_ALLOW_BIG_LDS((&conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), smem);
   PP_LAUNCH((conv_igemm_kernel<T, OT, WC, WP, TC, TP, M32, KC>), grid, dim3(NT), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }

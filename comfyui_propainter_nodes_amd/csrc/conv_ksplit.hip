@@ -231,8 +231,7 @@ template <typename OT>
 static int launch_ksplit_t(void* stream, const ConvK& k, int Z) {
   constexpr size_t smem = (size_t)kKS * 3 * (32 + 128) * 32 * sizeof(half_t);  // 120 KiB
   dim3 grid((unsigned)((k.M + 31) / 32), (unsigned)((k.Cout + 127) / 128), (unsigned)Z);
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_ksplit_kernel<OT>), smem), true);
-  (void)lds_ok;
+  PP_ALLOW_BIG_LDS((&conv_ksplit_kernel<OT>), smem);
   PP_LAUNCH((conv_ksplit_kernel<OT>), grid, dim3(kKS * 256), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }

@@ -292,8 +292,7 @@ static int launch_split_cfg(void* stream, const ConvK& k, int Z) {
   constexpr int BCP = (BC + NT / 8 - 1) / (NT / 8) * (NT / 8);
   const size_t smem = (size_t)(2 * BP + 3 * BCP) * 128;
   dim3 grid((unsigned)(((k.M + BP - 1) / BP) * ((k.Cout + BC - 1) / BC)), 1u, (unsigned)Z);
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&conv_split_kernel<OT, WC, WP, TC, TP>), smem), true);
-  (void)lds_ok;
+  PP_ALLOW_BIG_LDS((&conv_split_kernel<OT, WC, WP, TC, TP>), smem);
   PP_LAUNCH((conv_split_kernel<OT, WC, WP, TC, TP>), grid, dim3(NT), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }

@@ -306,8 +306,7 @@ static int launch_deform_cfg(void* stream, const DeformSrc& d, const ConvK& k) {
   constexpr size_t red = (size_t)(KS - 1) * NW * 8 * TP * 64 * sizeof(f4);
   constexpr size_t smem = ring > red ? ring : red;
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + 127) / 128), 1u);
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&deform_conv_kernel<OT, NW, KS, TP>), smem), true);
-  (void)lds_ok;
+  PP_ALLOW_BIG_LDS((&deform_conv_kernel<OT, NW, KS, TP>), smem);
   PP_LAUNCH((deform_conv_kernel<OT, NW, KS, TP>), grid, dim3(KS * NW * 64), smem, stream, d, k);
   return pp_check_launch("pp_deform_conv");
 }

@@ -31,12 +31,19 @@ int pp_check_launch(const char* what) {
   return PP_OK;
 }
 
-void pp_allow_big_lds(const void* func, size_t bytes) {
+void pp_allow_big_lds(const void* func, size_t bytes, std::atomic<unsigned long long>* mask) {
 #ifndef PP_EMU
-  if (bytes > 48 * 1024) hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (bytes <= 48 * 1024) return;
+  int dev = 0;
+  hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask->load(std::memory_order_acquire) & bit) return;
+  hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  mask->fetch_or(bit, std::memory_order_release);
 #else
   (void)func;
   (void)bytes;
+  (void)mask;
 #endif
 }
 
@@ -67,6 +74,9 @@ static void load_options() {
     else if (e[0] == 'c') o.tile = 6;
     else o.tile = e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
   }
+  o.gemm = tri("PP_CONV_GEMM");
+  o.gemm_cfg = 0;
+  if (const char* e = getenv("PP_CONV_GEMM_CFG")) o.gemm_cfg = atoi(e);
   o.deform_xcd = 1;
   if (const char* e = getenv("PP_DEFORM_XCD")) o.deform_xcd = e[0] != '0';
   std::lock_guard<std::mutex> lock(g_options_mutex);

@@ -10,6 +10,8 @@
 //   PP_CONV_DIRECT   0 | force   <= 4-output-channel streaming kernel off / regardless of the image size
 //   PP_CONV_ORDER    launch      flat-tile kernels: work-groups in launch order (pixel tiles first) instead of XCD-contiguous,
 //                                channel-tile-adjacent order (conv_common.h: flat_tile_of)
+//   PP_CONV_GEMM     0 | force   the GEMM kernel for 1x1 f16 layers (conv_gemm_f16.hip) off / for every eligible layer whatever its size
+//   PP_CONV_GEMM_CFG 1..5        pin one tile configuration of that kernel (tuning; conv_gemm_f16.hip: launch_gemm_t)
 //   PP_CONV_TRACE    (set)       print which convolution kernel family ran (debugging aid)
 //   PP_DEFORM_XCD    0           pp_deform_cols / pp_deform_conv walk their pixel blocks in launch order instead of XCD-contiguous order
 #pragma once
@@ -23,6 +25,8 @@ struct Options {
   int direct;   // 0 off, 1 auto, 2 force
   int trace;
   int conv_order;  // 1 (default): XCD-contiguous, channel tiles adjacent; 0: launch order
+  int gemm;        // 0 off, 1 auto, 2 force
+  int gemm_cfg;    // 0 auto, 1..5 pinned
   int deform_xcd;  // 1 (default): the deformable-sampling kernels walk their pixel blocks in XCD-contiguous order
 };
 const Options& options();

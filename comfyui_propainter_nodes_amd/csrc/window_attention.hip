@@ -721,8 +721,7 @@ static int launch_window_attention_f16(void* stream, const pp_window_attention_p
   k.nx = nqb > npair ? nqb : npair;
   k.npairs = kHeads * nwin;
   const int nwg = 8 * ((k.npairs + 7) / 8) * k.nx;
-  static const bool lds_ok = (pp_allow_big_lds(reinterpret_cast<const void*>(&window_attention_f16_kernel), kAtSmem), true);
-  (void)lds_ok;
+  PP_ALLOW_BIG_LDS((&window_attention_f16_kernel), kAtSmem);
 #ifdef PP_ATTN_TRACE
   static long long* trace = nullptr;
   const size_t tbytes = (2 + 2 * 100 * 8) * sizeof(long long);

@@ -214,6 +214,37 @@ def test_many_channel_tiles(backend, order, pp_knobs):
         assert err <= (4e-3 if dt == torch.float16 else 2e-5) * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("cfg", ["1", "2", "3", "4", "5", "6"])
+def test_gemm_kernel_equals_flat_kernel(backend, cfg, pp_knobs):
+    """r04: the GEMM kernel of the 1x1 f16 layers (conv_gemm_f16.hip: the transformer's Linear layers) issues the flat kernel's
+    MFMAs in the flat kernel's order, so it must reproduce it BIT FOR BIT -- every tile configuration, on shapes that exercise
+    the channel tail of the last chunk (C % 32 = 8, the 1960-channel fc2), a partial last stage (odd chunk count with two
+    chunks per barrier), pixel / channel tiles that end inside the problem, one chunk only, fp32 output and a fused epilogue."""
+    g = torch.Generator().manual_seed(41)
+    shapes = [  # N, H, W, C, Cout, out dtype, epilogue
+        (1, 13, 23, 104, 200, torch.float16, None),          # 4 chunks (3.25), partial tiles both ways
+        (2, 9, 17, 160, 264, torch.float16, "add"),          # 5 chunks: partial last stage when KC = 2
+        (1, 6, 11, 24, 136, torch.float32, None),            # one (partial) chunk, fp32 output
+        (1, 20, 33, 328, 96, torch.float16, None),           # 10.25 chunks: the ring wraps several times
+    ]
+    for N, H, W, C, Cout, odt, epi in shapes:
+        x = torch.randn(N, H, W, C, generator=g).half().to(backend)
+        wgt = torch.randn(Cout, C, 1, 1, generator=g) * 0.1
+        b = torch.randn(Cout, generator=g)
+        aux = torch.randn(N, H, W, Cout, generator=g).to(odt).to(backend)
+        spec = ops.make_conv_spec(wgt, b, torch.float16).to(backend)
+        outs = []
+        for knobs in (dict(PP_CONV_GEMM="0", PP_CONV_GEMM_CFG="0"), dict(PP_CONV_GEMM="force", PP_CONV_GEMM_CFG=cfg)):
+            pp_knobs(PP_CONV_KSPLIT="0", **knobs)
+            out = torch.full((N, H, W, Cout), float("nan"), device=backend, dtype=odt)
+            ops.conv2d(spec, [x], out, act="gelu", **({"epi": "add", "aux1": aux} if epi else {}))
+            outs.append(out.cpu())
+        assert torch.equal(outs[0], outs[1]), (N, H, W, C, Cout, (outs[0].float() - outs[1].float()).abs().max())
+        ref = F.conv2d(x.cpu().double().permute(0, 3, 1, 2), wgt.half().double(), b.double()).permute(0, 2, 3, 1)
+        ref = torch.nn.functional.gelu(ref) + (aux.cpu().double() if epi else 0)
+        assert (outs[1].double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("halo", ["0", "force"])
 def test_epilogue_from_a_channel(backend, halo, pp_knobs):
     """`epi_from` (ABI v6): RAFT's GRU computes the z and r gates (update.py:41-43) in ONE 256-channel PP_F32X2 convolution
