@@ -292,7 +292,7 @@ def main():
         fr_d = D.Slab(lo, torch.from_numpy(frames_u8[lo:hi]).to(dev))
 
         def step():
-            return D.run_distributed(backend, cfg, fr_d, fm_d, md_d)
+            return D.run_distributed(backend, cfg, fr_d, fm_d, md_d, gather_root=0)   # only rank 0 returns the clip
     else:
         fr_d = torch.from_numpy(frames_u8).to(dev)
 

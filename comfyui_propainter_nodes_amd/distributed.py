@@ -29,6 +29,7 @@ clip instead of the 2 x 2.4 GB an all_gather of whole per-rank slabs delivers to
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -187,10 +188,7 @@ def _interval(rng: tuple[int, int], halo: int, n: int) -> tuple[int, int]:
     return (a, a) if b <= a else (max(0, a - halo), min(n, b + halo))
 
 
-def _halo_exchange(own: torch.Tensor, ranges: list[tuple[int, int]], rank: int, need: list[tuple[int, int]]):
-    """Sub-generator: `own` holds this rank's rows `ranges[rank]` of a clip-long tensor (row = dim 0); every rank r needs
-    the rows `need[r]` (an interval containing its own range).  Each rank sends a peer exactly the part of its rows the
-    peer needs -- for halos of a few frames that is the two neighbours only -- and returns a Slab over `need[rank]`."""
+def _halo_plan(own: torch.Tensor, ranges: list[tuple[int, int]], rank: int, need: list[tuple[int, int]]):
     a, b = ranges[rank]
     lo, hi = need[rank]
     sends, recvs = {}, {}
@@ -203,21 +201,45 @@ def _halo_exchange(own: torch.Tensor, ranges: list[tuple[int, int]], rank: int, 
         x, y = max(ra, lo), min(rb, hi)                       # peer r's rows that I need
         if y > x:
             recvs[r] = ((y - x,) + tuple(own.shape[1:]), own.dtype)
-    got = yield ("p2p", sends, recvs)
+    return sends, recvs
+
+
+def _halo_buffer(own: torch.Tensor, ranges, rank: int, need, poison: bool = False) -> Slab:
+    a, b = ranges[rank]
+    lo, hi = need[rank]
     buf = torch.empty((hi - lo,) + tuple(own.shape[1:]), dtype=own.dtype, device=own.device)
+    if poison and buf.is_floating_point():
+        buf.fill_(float("nan"))          # (tests: a window that reads a halo row before it landed cannot go unnoticed)
     if b > a:
         buf[a - lo:b - lo] = own
-    for r, (ra, rb) in enumerate(ranges):
-        if r in recvs:
-            x, y = max(ra, lo), min(rb, hi)
-            buf[x - lo:y - lo] = got[r]
     return Slab(lo, buf)
 
 
-def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8):
+def _halo_fill(slab: Slab, got: dict, ranges, recvs) -> None:
+    lo, hi = slab.lo, slab.hi
+    for r, (ra, rb) in enumerate(ranges):
+        if r in recvs:
+            x, y = max(ra, lo), min(rb, hi)
+            slab.t[x - lo:y - lo] = got[r]
+
+
+def _halo_exchange(own: torch.Tensor, ranges: list[tuple[int, int]], rank: int, need: list[tuple[int, int]]):
+    """Sub-generator: `own` holds this rank's rows `ranges[rank]` of a clip-long tensor (row = dim 0); every rank r needs
+    the rows `need[r]` (an interval containing its own range).  Each rank sends a peer exactly the part of its rows the
+    peer needs -- for halos of a few frames that is the two neighbours only -- and returns a Slab over `need[rank]`."""
+    sends, recvs = _halo_plan(own, ranges, rank, need)
+    got = yield ("p2p", sends, recvs)
+    slab = _halo_buffer(own, ranges, rank, need)
+    _halo_fill(slab, got, ranges, recvs)
+    return slab
+
+
+def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8,
+             gather_root: int | None = None):
     """Generator implementing phases A..D for one rank.  `frames_u8` is the whole clip [T,H,W,3] or a `Slab` holding at
     least `frames_needed(plan)`; the masks are clip-long (they are replicated host plumbing, 0.23 MB per frame).
-    Returns the full composed clip (uint8 [T,H,W,3]) on every rank."""
+    Returns the full composed clip (uint8 [T,H,W,3]) on every rank; with `gather_root` = r only rank r receives the clip
+    (every other rank sends its own frames to r and returns None): the node's return value lives on one rank (r04)."""
     T = plan.T
     F0, F1 = plan.frames
     fa, fb = plan.flows
@@ -281,13 +303,19 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
         enc_own = None
     if enc_own is None:   # an idle rank still takes part in the exchange: the geometry is a function of the frame size
         enc_own = torch.zeros((0,) + tuple(backend.enc_tail(hw)), device=dev, dtype=getattr(backend, "act_dtype", torch.float16))
-    # x2: encoder features + updated masks of the frames this rank's windows read (+-45 frames at the defaults)
-    enc_s = yield from _halo_exchange(enc_own, plan.frame_ranges, plan.rank, need2)
+    # x2: encoder features + updated masks of the frames this rank's windows read (+-45 frames at the defaults).  The masks
+    # (0.23 MB per frame) travel first, blocking; the features (0.35 GB per seam at 640x360) are POSTED and travel under the
+    # feature propagation of the windows whose local frames are all this rank's own (r04: it was a blocking exchange between
+    # phases B and C) -- feature propagation reads the local frames of a window only (propainter.py:118-231); the reference
+    # frames, up to 40 frames away, are first read by the transformer
     upd_s = yield from _halo_exchange(upd, plan.frame_ranges, plan.rank, need2)
+    enc_sends, enc_recvs = _halo_plan(enc_own, plan.frame_ranges, plan.rank, need2)
+    enc_handle = yield ("p2p_start", enc_sends, enc_recvs)
+    enc_s = _halo_buffer(enc_own, plan.frame_ranges, plan.rank, need2, poison=os.environ.get("PP_POISON_HALOS") == "1")
     S0, S1 = need2[plan.rank]
     # ---- C: the windows centred in the owned frames, on a clip state over [S0, S1) only --------------------------
     # x3 (window outputs that land on frames of another rank) is posted as soon as the SEAM windows are done and
-    # travels under the interior windows; it is waited for where compose needs it
+    # travels under the transformer of the interior windows; it is waited for where compose needs it
     mine = [wi for wi, f in enumerate(centers) if F0 <= f < F1]
     exports: list[dict[int, list[tuple[int, int]]]] = [dict() for _ in range(plan.world)]   # [src][dst] -> [(wi, idx)]
     for wi, (nb, _) in enumerate(schedule):
@@ -298,7 +326,7 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
                 exports[src].setdefault(dst, []).append((wi, idx))
     seam_set = {wi for lst in exports[plan.rank].values() for wi, _ in lst}
     seam = [wi for wi in mine if wi in seam_set]
-    interior = [wi for wi in mine if wi not in seam_set]
+    interior = [wi for wi in mine if wi not in seam_set]     # (their local frames are all owned: they export nothing)
     H, W = hw
     pred_tail = tuple(backend.pred_tail(hw))
     recvs = {src: ((len(exports[src][plan.rank]),) + pred_tail, getattr(backend, "act_dtype", torch.float16))
@@ -312,12 +340,22 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
             flows_loc[:, x - S0:y - S0] = pred_s.rows(x, y).transpose(0, 1)
         st = backend.make_state(enc_s.t, flows_loc, masks_dilated_u8[S0:S1].contiguous(), upd_s.t)
         loc = {wi: ([i - S0 for i in schedule[wi][0]], [i - S0 for i in schedule[wi][1]]) for wi in mine}
+    local_props = {}
+    if interior:        # under x2
+        lp = backend.propagate_windows(st, [loc[wi][0] for wi in interior])
+        local_props.update({wi: lp[j] for j, wi in enumerate(interior)})
+    got = yield ("p2p_wait", enc_handle)
+    _halo_fill(enc_s, got, plan.frame_ranges, enc_recvs)
+    if mine and hasattr(backend, "enc_landed"):
+        backend.enc_landed(st, enc_s.t)      # (a backend whose state copied the features refreshes its copy)
 
     def run_windows(group):
-        if group:
-            lp = backend.propagate_windows(st, [loc[wi][0] for wi in group])
-            for j, wi in enumerate(group):
-                preds[wi] = backend.forward_window(st, loc[wi][0], loc[wi][1], lp[j])
+        todo = [wi for wi in group if wi not in local_props]
+        if todo:
+            lp = backend.propagate_windows(st, [loc[wi][0] for wi in todo])
+            local_props.update({wi: lp[j] for j, wi in enumerate(todo)})
+        for wi in group:
+            preds[wi] = backend.forward_window(st, loc[wi][0], loc[wi][1], local_props.pop(wi))
 
     run_windows(seam)
     sends = {dst: torch.stack([preds[wi][schedule[wi][0].index(idx)] for wi, idx in lst], 0)
@@ -345,7 +383,14 @@ def run_rank(backend, plan: ShardPlan, config: ProPainterConfig, frames_u8, flow
         backend.compose(comp, p, [i - F0 for i in ids], [0 if seen[i] else 1 for i in ids], md_own, orig)
         for i in ids:
             seen[i] = True
-    # x4: every rank returns the whole composed clip (uint8 frames: 0.7 MB each)
+    # x4: the composed uint8 frames (0.7 MB each): to every rank (all_gather), or to the one rank that returns the clip
+    if gather_root is not None:
+        if plan.rank != gather_root:
+            yield ("p2p", ({gather_root: comp} if F1 > F0 else {}), {})
+            return None
+        recvs = {r: ((b - a,) + hw + (3,), torch.uint8) for r, (a, b) in enumerate(plan.frame_ranges) if r != gather_root and b > a}
+        got = yield ("p2p", {}, recvs)
+        return torch.cat([comp if r == gather_root else got[r] for r, (a, b) in enumerate(plan.frame_ranges) if b > a], 0)
     max_frames = max(b - a for a, b in plan.frame_ranges)
     g_comp = yield _pad_first(comp, max_frames)
     return torch.cat([g[:b - a] for g, (a, b) in zip(g_comp, plan.frame_ranges)], 0)
@@ -363,14 +408,15 @@ def frames_needed(plan: ShardPlan) -> tuple[int, int]:
 # ------------------------------------------------------------------------------------------------
 # runners
 # ------------------------------------------------------------------------------------------------
-def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8, group=None):
+def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8, group=None,
+                    gather_root: int | None = None):
     """One rank of a torch.distributed job (backend "nccl" = RCCL on the MI355X, "gloo" in CPU tests).  all_gather for the
     two whole-clip exchanges, grouped point-to-point sends / receives (xGMI is point to point: a seam travels over the one
     link between the two neighbours) for the halos."""
     import torch.distributed as dist
 
     plan = ShardPlan(config.video_length, config.subvideo_length, dist.get_world_size(group), dist.get_rank(group))
-    gen = run_rank(backend, plan, config, frames_u8, flow_masks_u8, masks_dilated_u8)
+    gen = run_rank(backend, plan, config, frames_u8, flow_masks_u8, masks_dilated_u8, gather_root=gather_root)
     via_host = dist.get_backend(group) == "gloo"  # gloo moves host memory: stage through the host (tests only)
     dev = (frames_u8.t if isinstance(frames_u8, Slab) else frames_u8).device
 
@@ -410,15 +456,26 @@ def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8,
         return stop.value
 
 
-def run_simulated(make_backend, world: int, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8):
+def run_simulated(make_backend, world: int, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8,
+                  gather_root: int | None = None):
     """N virtual ranks advanced in lock-step inside ONE process (functional testing on a single GPU)."""
     plans = [ShardPlan(config.video_length, config.subvideo_length, world, r) for r in range(world)]
-    gens = [run_rank(make_backend(r), plans[r], config, frames_u8, flow_masks_u8, masks_dilated_u8) for r in range(world)]
+    gens = [run_rank(make_backend(r), plans[r], config, frames_u8, flow_masks_u8, masks_dilated_u8, gather_root=gather_root)
+            for r in range(world)]
     vals = [next(g) for g in gens]
     results = [None] * world
-    while any(r is None for r in results):
+    done = [False] * world
+
+    class _Pending:     # what a rank holds between p2p_start and p2p_wait: opaque, so it cannot read a buffer before the wait
+        def __init__(self, reply):
+            self._reply = reply
+
+    while not all(done):
         nxt = []
         for r, g in enumerate(gens):
+            if done[r]:
+                nxt.append(None)
+                continue
             if isinstance(vals[r], tuple) and vals[r][0] == "p2p_start":
                 # every rank posts in the same lock-step round: deliver at once, hand the result back at the wait
                 _, _, recvs = vals[r]
@@ -428,8 +485,9 @@ def run_simulated(make_backend, world: int, config: ProPainterConfig, frames_u8,
                     assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (src, r, tuple(t.shape), shape)
                     reply[src] = t.clone()
                 assert all(r in vals[dst][2] for dst in vals[r][1]), "a send without a matching receive"
+                reply = _Pending(reply)
             elif isinstance(vals[r], tuple) and vals[r][0] == "p2p_wait":
-                reply = vals[r][1]
+                reply = vals[r][1]._reply
             elif isinstance(vals[r], tuple):    # neighbour exchange: what every peer addressed to rank r
                 _, _, recvs = vals[r]
                 reply = {}
@@ -444,6 +502,196 @@ def run_simulated(make_backend, world: int, config: ProPainterConfig, frames_u8,
                 nxt.append(g.send(reply))
             except StopIteration as stop:
                 results[r] = stop.value
+                done[r] = True
                 nxt.append(None)
         vals = nxt
     return results
+
+
+# ------------------------------------------------------------------------------------------------
+# in-process multi-device runner: ONE process drives N GPUs (the drop-in node itself shards, PP_GPUS=N)
+# ------------------------------------------------------------------------------------------------
+class _Mailbox:
+    """Rendezvous of the rank threads: (sequence number, src, dst) -> (tensor, ready event).  A failing rank poisons the box so
+    that its peers stop waiting."""
+
+    def __init__(self):
+        import threading
+
+        self.cv = threading.Condition()
+        self.box: dict = {}
+        self.failed: BaseException | None = None
+
+    def put(self, key, item) -> None:
+        with self.cv:
+            self.box[key] = item
+            self.cv.notify_all()
+
+    def take(self, key, timeout_s: float = 900.0):
+        import time
+
+        t_end = time.monotonic() + timeout_s
+        with self.cv:
+            while key not in self.box:
+                if self.failed is not None:
+                    raise RuntimeError("a peer rank failed") from self.failed
+                if time.monotonic() > t_end:
+                    raise TimeoutError(f"no message {key} within {timeout_s} s")
+                self.cv.wait(0.5)
+            return self.box.pop(key)
+
+    def fail(self, exc: BaseException) -> None:
+        with self.cv:
+            if self.failed is None:
+                self.failed = exc
+            self.cv.notify_all()
+
+
+class _PeerLink:
+    """The receiving side of the peer copies of one rank thread.  A copy between two GPUs runs on a SIDE stream of the source
+    device (torch issues a cross-device copy on the source device's current stream of the calling thread) bracketed by a side
+    stream of this rank's device, so neither the sender's nor the receiver's compute stream waits for it until the receiver asks
+    for the data (`finish`): a posted exchange travels over xGMI under the kernels both sides keep launching."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.cuda = device.type == "cuda"
+        self.side = torch.cuda.Stream(device) if self.cuda else None
+        self.src_streams: dict = {}
+
+    def ready_event(self):
+        """(sender side) the data produced so far on this rank's compute stream is complete."""
+        if not self.cuda:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def fetch(self, t: torch.Tensor, ev, shape, dtype) -> tuple:
+        """Start copying peer tensor `t` (complete at `ev`) to this device; returns (buffer, done event)."""
+        assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (tuple(t.shape), tuple(shape), t.dtype, dtype)
+        if not self.cuda:
+            return t.clone(), None
+        if not t.is_cuda:
+            return t.to(self.device, non_blocking=True), None
+        if t.device == self.device:      # ranks sharing a device (virtual ranks): an ordinary copy on this rank's side stream
+            if ev is not None:
+                self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                buf = torch.empty(shape, dtype=dtype, device=self.device)
+                buf.copy_(t, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.side)
+            t.record_stream(self.side)
+            return buf, done
+        s_src = self.src_streams.get(t.device)
+        if s_src is None:
+            s_src = self.src_streams[t.device] = torch.cuda.Stream(t.device)
+        if ev is not None:
+            s_src.wait_event(ev)
+        # torch issues the copy on the SOURCE device's current stream and makes the destination device's current stream wait
+        # for it: both are side streams here, `done` (recorded on this device's side stream) therefore covers the copy
+        with torch.cuda.stream(self.side), torch.cuda.stream(s_src):
+            buf = torch.empty(shape, dtype=dtype, device=self.device)
+            buf.copy_(t, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        t.record_stream(s_src)          # the sender may drop its tensor: the allocator must not reuse it under the copy
+        return buf, done
+
+    def finish(self, buf: torch.Tensor, done) -> torch.Tensor:
+        if done is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)
+            buf.record_stream(cur)
+        return buf
+
+
+def run_multi_device(backends: list, config: ProPainterConfig, load_slab, flow_masks_u8, masks_dilated_u8, devices: list,
+                     gather_root: int | None = 0):
+    """ONE process, N devices, one thread per device: the sharded driver behind the node (PP_GPUS=N) -- a ComfyUI process that owns
+    the 8 GPUs of a node partitions a long clip over them without torch.distributed (north_star: "the pipeline partitions clips
+    over the 8 GPUs of one node", propainter_nodes.py:109 picks ONE device per call).  Same plan, same generator (`run_rank`), same
+    seam exchanges as the one-process-per-GPU runner; the exchanges are peer copies (hipMemcpyPeer over xGMI) ordered by events
+    instead of RCCL point-to-point calls, the whole-clip all_gather is replaced by a gather to `gather_root`.
+
+    backends[r]     stage functions on devices[r] (GpuBackend over that device's models)
+    load_slab(r, lo, hi, device) -> uint8 frames [hi-lo, H, W, 3] of the clip on that device (each rank uploads only what it needs)
+    masks           clip-long uint8 tensors (any device / host): copied to every device
+    Devices may repeat (virtual ranks on one GPU: the functional test of this path on a 1-GPU box).
+    Returns the composed clip on devices[gather_root] (gather_root None: a list with every rank's copy)."""
+    import threading
+
+    world = len(devices)
+    devices = [torch.device(d) for d in devices]
+    T = config.video_length
+    box = _Mailbox()
+    results: list = [None] * world
+    errors: list = [None] * world
+
+    def rank_main(r: int) -> None:
+        dev = devices[r]
+        try:
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)          # (the HIP current device is per thread)
+                # a compute stream of its own per rank: ranks that share a device (virtual ranks) must not meet on the legacy
+                # default stream -- a launch there while another rank captures a hipGraph invalidates the capture
+                compute = torch.cuda.Stream(dev)
+                compute.wait_stream(torch.cuda.default_stream(dev))
+                torch.cuda.set_stream(compute)
+            link = _PeerLink(dev)
+            plan = ShardPlan(T, config.subvideo_length, world, r)
+            lo, hi = frames_needed(plan)
+            fr = Slab(lo, load_slab(r, lo, hi, dev))
+            fm = flow_masks_u8.to(dev, non_blocking=True)
+            md = masks_dilated_u8.to(dev, non_blocking=True)
+            gen = run_rank(backends[r], plan, config, fr, fm, md, gather_root=gather_root)
+            seq = 0
+
+            def post(sends, recvs):
+                nonlocal seq
+                ev = link.ready_event() if sends else None
+                for peer, ten in sends.items():
+                    box.put((seq, r, peer), (ten, ev))
+                pend = {}
+                for peer, (shape, dtype) in recvs.items():
+                    ten, pev = box.take((seq, peer, r))
+                    pend[peer] = link.fetch(ten, pev, shape, dtype)
+                seq += 1
+                return pend
+
+            def finish(pend):
+                return {peer: link.finish(buf, done) for peer, (buf, done) in pend.items()}
+
+            try:
+                t = next(gen)
+                while True:
+                    if isinstance(t, tuple) and t[0] == "p2p_start":
+                        out = post(t[1], t[2])
+                    elif isinstance(t, tuple) and t[0] == "p2p_wait":
+                        out = finish(t[1])
+                    elif isinstance(t, tuple):
+                        out = finish(post(t[1], t[2]))
+                    else:       # all_gather (gather_root None): every rank's tensor to every rank
+                        sends = {p: t for p in range(world) if p != r}
+                        recvs = {p: (tuple(t.shape), t.dtype) for p in range(world) if p != r}
+                        got = finish(post(sends, recvs))
+                        out = [t if p == r else got[p] for p in range(world)]
+                    t = gen.send(out)
+            except StopIteration as stop:
+                results[r] = stop.value
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()     # the caller reads the result from another thread / stream
+        except BaseException as e:  # noqa: BLE001 -- surfaced by the caller
+            errors[r] = e
+            box.fail(e)
+
+    threads = [threading.Thread(target=rank_main, args=(r,), name=f"pp-rank{r}", daemon=True) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return results if gather_root is None else results[gather_root]

@@ -15,6 +15,7 @@ tests), while bench.py times individual launches with HIP events, and with PP_GR
 from __future__ import annotations
 
 import os
+import threading
 from collections import OrderedDict
 from typing import Callable
 
@@ -23,6 +24,7 @@ import torch
 from . import ops
 
 _MAX_GRAPHS = int(os.environ.get("PP_GRAPH_CACHE", "12"))
+_CAPTURE_LOCK = threading.Lock()
 
 
 def enabled(*tensors: torch.Tensor) -> bool:
@@ -67,14 +69,21 @@ class GraphCache:
             s = torch.cuda.Stream(inputs[0].device)
             s.wait_stream(torch.cuda.current_stream())
             ops.PIN_DEVICE_INTS += 1      # index tensors requested from here on are baked into the graph: never evicted
+            # one capture at a time per process: torch registers the device's RNG state with a capture and refuses a second
+            # concurrent one ("Cannot register the state during capturing stage") -- the rank threads of
+            # distributed.run_multi_device capture their sweeps at about the same moment
+            _CAPTURE_LOCK.acquire()
             try:
                 with torch.cuda.stream(s):
                     fn(*static_in)
                 torch.cuda.current_stream().wait_stream(s)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # capture stream on THIS device (torch's default capture stream lives on whichever device captured first);
+                # thread-local error mode: other threads (the other ranks of run_multi_device, ComfyUI's own) may allocate meanwhile
+                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                     out = fn(*static_in)
             finally:
+                _CAPTURE_LOCK.release()
                 ops.PIN_DEVICE_INTS -= 1
             e = _Entry(g, static_in, out)
             self._entries[key] = e

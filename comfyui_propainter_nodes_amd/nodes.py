@@ -247,6 +247,53 @@ class _HostImageSink:
         return self.image
 
 
+def _shard_devices(config: ProPainterConfig, device: torch.device) -> list:
+    """PP_GPUS=N (or "all"): the devices ONE node call spreads a long clip over (r04: the drop-in itself shards; the reference
+    picks one device per call, propainter_nodes.py:109).  Sharding follows the reference's own sub-video chunks, so it applies
+    when the clip has at least two of them (video_length > subvideo_length <= 100: the reference's local-reference mode);
+    shorter clips stay on one GPU.  PP_GPUS_VIRTUAL=1 lets ranks share a device (functional tests on a 1-GPU box)."""
+    want = os.environ.get("PP_GPUS", "1").strip().lower()
+    if want in ("", "0", "1") or TRACE is not None or device.type != "cuda":
+        return [device]
+    have = torch.cuda.device_count()
+    n = have if want == "all" else int(want)
+    sv = config.subvideo_length
+    nchunks = (config.video_length + sv - 1) // sv
+    if sv > 100 or nchunks < 2:
+        return [device]
+    n = min(n, nchunks)
+    if os.environ.get("PP_GPUS_VIRTUAL") == "1":
+        return [device] * n
+    first = device.index if device.index is not None else torch.cuda.current_device()
+    order = [first] + [i for i in range(have) if i != first]
+    return [torch.device("cuda", i) for i in order[:min(n, have)]]
+
+
+def _run_sharded(devices: list, config: ProPainterConfig, load_slab, fm, md, tm: _Timer):
+    """One clip over several GPUs from inside the node call: distributed.run_multi_device (one thread per device, sub-video
+    shards, seam-only peer copies, the composed frames gathered on the first device)."""
+    from . import distributed as D
+    from .pipeline import models_from_state_dicts
+    from . import weights as W
+
+    virtual = len({str(d) for d in devices}) < len(devices)
+    backends = []
+    for d in devices:
+        if virtual:     # ranks sharing a device must not share a model object (its captured hipGraphs own static buffers)
+            sds, prov = W.get_state_dicts(0)
+            m = models_from_state_dicts(sds, d, config.fp16, prov)
+        else:
+            m = initialize_models(d, config.fp16)
+        backends.append(D.GpuBackend(m, config))
+    comp = D.run_multi_device(backends, config, load_slab, fm, md, devices, gather_root=0)
+    tm.mark(f"pipeline({len(devices)} ranks)")
+    out = _output(comp, fm, md)
+    tm.mark("output(u8->float, D2H)")
+    tm.done()
+    return out
+
+
+
 TRACE: dict | None = None  # debugging / test aid: when a dict, the next node call leaves its stage tensors in it
 
 
@@ -315,6 +362,24 @@ class ProPainterInpaint:
         image_config = ImageConfig(width, height, mask_dilates, flow_mask_dilates, input_size, video_length)
         config = ProPainterConfig(ref_stride, neighbor_length, subvideo_length, raft_iter, fp16, video_length, device,
                                   image_config.process_size)
+        devices = _shard_devices(config, device)
+        if len(devices) > 1:
+            if _device_io_ok(image, image_config.process_size, input_size, mask):
+                m = mask.detach().to(device).contiguous()
+                fm = _expand_masks(ops.mask_dilate(m, flow_mask_dilates), video_length)
+                md = _expand_masks(ops.mask_dilate(m, mask_dilates), video_length)
+
+                def load_slab(rank, lo, hi, dev):   # each rank uploads and converts only the frames it needs
+                    return ops.frames_from_image(image[lo:hi].detach().to(dev).contiguous(), want_f32=False)[0]
+            else:
+                frames_u8, flow_masks, masks_dilated = prepare_frames_and_masks(image_to_uint8_frames(image), mask, image_config)
+                fm, md = torch.from_numpy(flow_masks).to(device), torch.from_numpy(masks_dilated).to(device)
+
+                def load_slab(rank, lo, hi, dev):
+                    return torch.from_numpy(frames_u8[lo:hi]).to(dev)
+            tm.mark("input(masks)")
+            print(f"\nProcessing  {config.video_length} frames on {len(devices)} GPUs...")
+            return _run_sharded(devices, config, load_slab, fm, md, tm)
         models = initialize_models(device, config.fp16)
         if _device_io_ok(image, image_config.process_size, input_size, mask):
             # one H2D of the fp32 IMAGE / MASK; uint8 conversion, [-1,1] scaling and mask dilation on the device
@@ -366,6 +431,26 @@ class ProPainterOutpaint:
                                            width_scale, height_scale)
         config = ProPainterConfig(ref_stride, neighbor_length, subvideo_length, raft_iter, fp16, video_length, device,
                                   image_config.outpaint_size)
+        devices = _shard_devices(config, device)
+        if len(devices) > 1:
+            if _device_io_ok(image, image_config.process_size, input_size):
+                (pw, ph), (hs, ws), flow_mask, mask = outpaint_geometry(image_config)
+                fm = _expand_masks(torch.from_numpy(flow_mask[None]).to(device), video_length)
+                md = _expand_masks(torch.from_numpy(mask[None]).to(device), video_length)
+
+                def load_slab(rank, lo, hi, dev):
+                    return ops.frames_from_image(image[lo:hi].detach().to(dev).contiguous(), (ph, pw), (hs, ws), want_f32=False)[0]
+            else:
+                frames_u8, flow_masks, masks_dilated = extrapolation(image_to_uint8_frames(image), image_config)
+                fm, md = torch.from_numpy(flow_masks).to(device), torch.from_numpy(masks_dilated).to(device)
+
+                def load_slab(rank, lo, hi, dev):
+                    return torch.from_numpy(frames_u8[lo:hi]).to(dev)
+            tm.mark("input(masks)")
+            print(f"\nProcessing  {config.video_length} frames on {len(devices)} GPUs...")
+            output_frames, output_masks, _ = _run_sharded(devices, config, load_slab, fm, md, tm)
+            output_width, output_height = config.process_size
+            return output_frames, output_masks, output_width, output_height
         models = initialize_models(device, config.fp16)
         if _device_io_ok(image, image_config.process_size, input_size):
             # outpaint fast path: the canvas is filled on the device, the two border masks are one static plane each

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import threading
 from collections import OrderedDict
 from dataclasses import dataclass
 
@@ -70,6 +71,7 @@ CONV_PROFILE: ConvProfile | None = None
 _INT_CACHE: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()   # bounded LRU: lists no captured graph refers to
 _INT_PINNED: dict = {}                                            # lists handed out while a hipGraph was being captured
 _INT_CACHE_MAX = 4096
+_INT_LOCK = threading.Lock()
 PIN_DEVICE_INTS = 0   # > 0 while graphs.GraphCache warms up / captures a sweep (its replays read these addresses)
 
 
@@ -80,22 +82,25 @@ def device_ints(values, device, dtype: torch.dtype = torch.int64) -> torch.Tenso
     problem shape; everything else lives in an LRU of `_INT_CACHE_MAX` entries, so a long-lived ComfyUI process does not
     grow without bound."""
     key = (tuple(values), str(device), dtype)
-    t = _INT_PINNED.get(key)
-    if t is not None:
+    with _INT_LOCK:      # (the rank threads of distributed.run_multi_device share the cache)
+        t = _INT_PINNED.get(key)
+        if t is not None:
+            return t
+        t = _INT_CACHE.get(key)
+        if t is None:
+            t = torch.tensor(list(values), dtype=dtype, device=device)
+            if t.is_cuda and not torch.cuda.is_current_stream_capturing():   # another thread / stream may be the next user: the upload must have landed
+                torch.cuda.current_stream(t.device).synchronize()
+        else:
+            _INT_CACHE.move_to_end(key)
+        if PIN_DEVICE_INTS > 0:
+            _INT_CACHE.pop(key, None)
+            _INT_PINNED[key] = t
+            return t
+        _INT_CACHE[key] = t
+        while len(_INT_CACHE) > _INT_CACHE_MAX:
+            _INT_CACHE.popitem(last=False)
         return t
-    t = _INT_CACHE.get(key)
-    if t is None:
-        t = torch.tensor(list(values), dtype=dtype, device=device)
-    else:
-        _INT_CACHE.move_to_end(key)
-    if PIN_DEVICE_INTS > 0:
-        _INT_CACHE.pop(key, None)
-        _INT_PINNED[key] = t
-        return t
-    _INT_CACHE[key] = t
-    while len(_INT_CACHE) > _INT_CACHE_MAX:
-        _INT_CACHE.popitem(last=False)
-    return t
 
 
 def dtype_code(dt: torch.dtype) -> int:

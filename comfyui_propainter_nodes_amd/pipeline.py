@@ -117,7 +117,7 @@ def initialize_models(device: torch.device, use_half: str = "enable", seed: int 
         ident = tuple((f, (weights.WEIGHT_DIR / f).stat().st_size, (weights.WEIGHT_DIR / f).stat().st_mtime_ns)
                       for f in weights.FILES.values())
     elif os.environ.get("PP_ALLOW_SYNTHETIC_WEIGHTS") == "1":
-        ident = ("synthetic", seed)
+        ident = ("synthetic", seed, os.environ.get("PP_SYNTHETIC_VARIANT", ""))
         _warn_once(f"no checkpoints in {weights.WEIGHT_DIR}: running on SYNTHETIC weights (seed {seed}); the output is "
                    "meaningless as an inpainting result (PP_ALLOW_SYNTHETIC_WEIGHTS=1 is set)")
     else:
@@ -126,8 +126,9 @@ def initialize_models(device: torch.device, use_half: str = "enable", seed: int 
             f"(release {weights.RELEASE_URL}) there. Set PP_ALLOW_SYNTHETIC_WEIGHTS=1 only for benchmarks / tests.")
     key = (str(device), ops.f32_split_enabled(), use_half, ident)
     if key not in _MODEL_CACHE:
-        if len(_MODEL_CACHE) >= 2:  # a stale entry pins three networks in HBM: keep at most the previous one
-            _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))
+        same_dev = [k for k in _MODEL_CACHE if k[0] == key[0]]
+        if len(same_dev) >= 2:  # a stale entry pins three networks in HBM: keep at most the previous one PER DEVICE
+            _MODEL_CACHE.pop(same_dev[0])
         sds, prov = weights.get_state_dicts(seed)
         _MODEL_CACHE[key] = models_from_state_dicts(sds, device, use_half, prov)
     return _MODEL_CACHE[key]

@@ -48,6 +48,14 @@ def check_node_case(case, fp16):
 
     if not (GOLD / f"{case}.npz").exists():
         pytest.skip(f"{case}.npz not minted")
+    evaluate_node_case(case, fp16, check=True)
+
+
+def evaluate_node_case(case, fp16, check=False, timer=None):
+    """Run the fixture's clip through OUR node method and compare with the reference's output; returns the metrics (and asserts
+    the suite's bounds when `check`).  `timer(seconds)` receives the wall time of the node call (tools/run_config.py)."""
+    import time
+
     g = np.load(GOLD / f"{case}.npz")
     P = json.loads(str(g["params_json"]))
     kind = str(g["kind"])
@@ -55,6 +63,7 @@ def check_node_case(case, fp16):
     common = {k: P[k] for k in ("mask_dilates", "flow_mask_dilates", "ref_stride", "neighbor_length", "subvideo_length",
                                 "raft_iter")}
     nodes.TRACE = tr = {}
+    t_call = time.perf_counter()
     try:
         if kind == "inpaint":
             out_img, out_a, out_b = nodes.ProPainterInpaint().propainter_inpainting(image, mask, P["width"], P["height"],
@@ -66,6 +75,8 @@ def check_node_case(case, fp16):
             out_b = None
     finally:
         nodes.TRACE = None
+    if timer is not None:
+        timer(time.perf_counter() - t_call)
     h, w = [int(v) for v in g["hw"]]
     T = P["T"]
     assert out_img.dtype == torch.float32 and tuple(out_img.shape) == (T, h, w, 3) and not out_img.is_cuda
@@ -104,6 +115,13 @@ def check_node_case(case, fp16):
     frac2 = float((diff > 2).mean()) if diff.size else 0.0
     print(f"{case} fp16={fp16}: gt_flow {e_gt:.2e} px, pred_flow max {e_pf:.2e} (outside the hole {e_out:.2e}) p99.9 {q_pf:.2e} mean {m_pf:.2e} px, upd_mask_frac {frac_m:.2e}, masked-pixel PSNR {p:.1f} dB, "
           f"max {int(diff.max()) if diff.size else 0} LSB, frac>2LSB {frac2:.2e}")
+    metrics = {"case": case, "fp16": fp16, "frames": T, "size": [w, h], "raft_flow_max_px": e_gt, "completed_flow_outside_hole_max_px": e_out,
+               "completed_flow_max_px": e_pf, "completed_flow_mean_px": m_pf, "updated_mask_mismatch": frac_m,
+               "psnr_db_inside_mask": round(float(p), 2), "max_lsb": int(diff.max()) if diff.size else 0, "frac_gt_2lsb": frac2,
+               "masks_bit_exact": True, "outside_mask_bit_exact": True,
+               "reference_seconds": float(g["ref_seconds"][0]) if "ref_seconds" in g else None}
+    if not check:
+        return metrics
     assert e_gt < 2e-3
     assert e_out < 2e-3                              # = the RAFT-flow bound, beyond the fixture's f16 storage rounding
     if T > 40:                                       # chaotic inside the hole (see the module docstring)
@@ -114,3 +132,4 @@ def check_node_case(case, fp16):
         assert m_pf < 5e-2 and e_pf < 3.0
     assert frac_m < 5e-3
     assert p >= 40.0 and frac2 < 1e-2
+    return metrics

@@ -10,6 +10,12 @@ Fixtures (tests/golden/cfg*_node.npz) were minted by running the reference's own
   cfg4_100f_node configs[3]'s mode at its size (r03): 100 frames > subvideo_length 80 -> local reference frames (ref_num 8),
                  flow completion in two sub-videos with 5-frame halos, image propagation with 10-frame halos
   mov_20f_node   per-frame (moving) MASK input (r03): mask.shape[0] == T, one dilation per mask frame
+  cfg3_80f_node  configs[2] IN FULL (r04): 80-frame outpaint 640x360 -> 768x360 (reference run 1267 s)
+  cfg5_90f_node  configs[4]'s size AND mode (r04): 90 frames of 1280x720 > subvideo_length 80, neighbor_length 20, raft_iter 20:
+                 local reference frames, RAFT in the reference's short clips of 4, two flow-completion / image-propagation
+                 sub-videos, 60x107 -> 60x108 token grid, 21-frame windows
+  cfg4_170f_node an INTERIOR sub-video at real size (r04): 170 frames of 640x360 -> sub-videos [0,80) [80,160) [160,170): the
+                 middle one has halos on both sides
 Tolerances (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact):
   RAFT flows 2e-3 px; updated masks <= 0.5 % differing pixels; final uint8 frames: exactly the input outside the dilated
   mask, PSNR >= 40 dB and >= 99 % within 2 LSB inside it; node mask outputs bit-exact.
@@ -53,7 +59,8 @@ def synthetic_models(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fp16", ["enable", "disable"])
-@pytest.mark.parametrize("case", ["cfg1_node", "cfg2_24f_node", "cfg3_12f_node", "cfg2_80f_node", "cfg4_100f_node", "mov_20f_node"])
+@pytest.mark.parametrize("case", ["cfg1_node", "cfg2_24f_node", "cfg3_12f_node", "cfg2_80f_node", "cfg4_100f_node", "mov_20f_node",
+                                  "cfg3_80f_node", "cfg5_90f_node", "cfg4_170f_node"])
 def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
     check_node_case(case, fp16)
 

@@ -17,6 +17,8 @@ from comfyui_propainter_nodes_amd import distributed as D
 from comfyui_propainter_nodes_amd import pipeline
 
 GOLD = Path(__file__).parent / "golden"
+# the halo rows of a posted exchange are NaN until they land: a window that reads one too early cannot pass
+os.environ.setdefault("PP_POISON_HALOS", "1")
 
 
 def test_shard_plan_is_the_reference_chunking():
@@ -47,7 +49,7 @@ def _cfg(T, nl, rs, sv):
     return pipeline.ProPainterConfig(rs, nl, sv, 2, "enable", T, torch.device("cpu"), (8, 6))
 
 
-def _worker(rank, world, port, T, nl, rs, sv, out_dir):
+def _worker(rank, world, port, T, nl, rs, sv, out_dir, gather_root=None):
     import sys
 
     sys.path.insert(0, str(Path(__file__).parent))
@@ -58,7 +60,7 @@ def _worker(rank, world, port, T, nl, rs, sv, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames, fm, md = _toy_inputs(T)
-    res = D.run_distributed(ToyBackend(), _cfg(T, nl, rs, sv), frames, fm, md)
+    res = D.run_distributed(ToyBackend(), _cfg(T, nl, rs, sv), frames, fm, md, gather_root=gather_root)
     torch.save(res, Path(out_dir) / f"r{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
@@ -92,6 +94,24 @@ def test_sharded_equals_single_rank_over_gloo(tmp_path, world, T, nl, rs, sv):
     assert not torch.equal(broken, ref), "the toy backend hides wrong flows"
 
 
+
+def test_gather_to_root_over_gloo(tmp_path):
+    """r04: `gather_root` = 0 (bench.py --gpus N, the node's multi-device mode): the composed frames travel to rank 0 only --
+    point-to-point sends instead of an all_gather that hands every rank the whole clip; rank 0 returns the single-rank result,
+    the other ranks None."""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).parent))
+    from toy_backend import ToyBackend
+
+    world, T, nl, rs, sv = 3, 37, 4, 2, 10
+    frames, fm, md = _toy_inputs(T)
+    ref = D.run_simulated(lambda r: ToyBackend(), 1, _cfg(T, nl, rs, sv), frames, fm, md)[0]
+    port = 29500 + (os.getpid() + 977) % 2000
+    mp.spawn(_worker, args=(world, port, T, nl, rs, sv, str(tmp_path), 0), nprocs=world, join=True)
+    assert torch.equal(torch.load(tmp_path / "r0.pt"), ref)
+    assert torch.load(tmp_path / "r1.pt") is None and torch.load(tmp_path / "r2.pt") is None
+
 @pytest.mark.parametrize("world,T,nl,rs,sv", [
     (4, 13, 4, 2, 3),    # 3-flow chunks: a 5-flow completion halo spans two neighbouring ranks (seam exchange x0)
     (5, 11, 4, 2, 2),    # 2-flow chunks, more ranks than a halo is long
@@ -114,6 +134,57 @@ def test_sharded_equals_single_rank_edge_cases(world, T, nl, rs, sv):
     sim = D.run_simulated(lambda r: ToyBackend(), world, _cfg(T, nl, rs, sv), frames, fm, md)
     for r, got in enumerate(sim):
         assert got.shape == ref.shape and torch.equal(got, ref), f"virtual rank {r} differs"
+
+
+
+@pytest.mark.parametrize("world,T,nl,rs,sv", [(2, 40, 6, 3, 10), (3, 37, 4, 2, 10), (4, 13, 4, 2, 3), (2, 60, 30, 10, 15), (8, 17, 6, 3, 100)])
+def test_multi_device_runner_equals_single_rank(world, T, nl, rs, sv):
+    """r04: the in-process multi-device runner behind the node's PP_GPUS=N (one THREAD per device, a mailbox + events + peer
+    copies instead of torch.distributed) drives the same generator: over CPU "devices" with the toy backend every plan must
+    reproduce the single-rank result bit for bit -- with the gather to rank 0 (the node's mode) and with every rank returning
+    the clip; each rank is handed only the frame slab it asked for."""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).parent))
+    from toy_backend import ToyBackend
+
+    frames, fm, md = _toy_inputs(T)
+    cfg = _cfg(T, nl, rs, sv)
+    ref = D.run_simulated(lambda r: ToyBackend(), 1, cfg, frames, fm, md)[0]
+    asked = []
+
+    def load_slab(rank, lo, hi, dev):
+        asked.append((rank, lo, hi))
+        return frames[lo:hi].clone()
+
+    devs = [torch.device("cpu")] * world
+    got = D.run_multi_device([ToyBackend() for _ in range(world)], cfg, load_slab, fm, md, devs, gather_root=0)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    for rank, lo, hi in asked:
+        assert (lo, hi) == D.frames_needed(D.ShardPlan(T, sv, world, rank))
+    everyone = D.run_multi_device([ToyBackend() for _ in range(world)], cfg, load_slab, fm, md, devs, gather_root=None)
+    assert len(everyone) == world and all(torch.equal(e, ref) for e in everyone)
+    # the lock-step simulator follows the gather-to-root protocol too: only the root returns the clip
+    sim = D.run_simulated(lambda r: ToyBackend(), world, cfg, frames, fm, md, gather_root=0)
+    assert torch.equal(sim[0], ref) and all(s is None for s in sim[1:])
+
+
+def test_multi_device_runner_surfaces_a_failing_rank():
+    """A rank that raises must not leave its peers waiting on the mailbox: the error reaches the caller."""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).parent))
+    from toy_backend import ToyBackend
+
+    class Broken(ToyBackend):
+        def complete(self, flows, masks):
+            raise RuntimeError("rank 1 lost its GPU")
+
+    T, nl, rs, sv = 40, 6, 3, 10
+    frames, fm, md = _toy_inputs(T)
+    with pytest.raises(RuntimeError):
+        D.run_multi_device([ToyBackend(), Broken()], _cfg(T, nl, rs, sv), lambda r, lo, hi, d: frames[lo:hi].clone(), fm, md,
+                           [torch.device("cpu")] * 2)
 
 
 def _assert_same_frames(got, single, exact, what):
@@ -209,6 +280,75 @@ def test_one_rank_rccl_group_runs_the_sharded_driver(hip_lib, tmp_path):
     mp.spawn(_gpu_worker, args=(1, port, str(tmp_path), "nccl"), nprocs=1, join=True)
     assert torch.equal(torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "single.pt"))
 
+
+
+def _multi_device_case(devices):
+    from comfyui_propainter_nodes_amd import weights
+
+    g = np.load(GOLD / "e2e_chunked.npz")
+    T, H, W, iters, nl, rs, sv, _, _, seed = [int(v) for v in g["params"]]
+    dev0 = devices[0]
+    sds = weights.synth_state_dicts(seed)
+    cfg = pipeline.ProPainterConfig(rs, nl, sv, iters, "enable", T, dev0, (W, H))
+    fr_h = torch.from_numpy(g["frames_u8"])
+    fm, md = (torch.from_numpy(g[k]).to(dev0) for k in ("flow_masks", "masks_dilated"))
+    single = pipeline.run_inpainting(pipeline.models_from_state_dicts(sds, dev0), fr_h.to(dev0), fm, md, cfg)
+    # one model object per rank (ranks that share a device must not share captured graphs), graphs ON: the runner gives every
+    # rank its own compute stream and captures with thread-local error mode
+    backends = [D.GpuBackend(pipeline.models_from_state_dicts(sds, d), cfg) for d in devices]
+    got = D.run_multi_device(backends, cfg, lambda r, lo, hi, d: fr_h[lo:hi].to(d), fm, md, devices, gather_root=0)
+    assert got.device == dev0
+    return got.cpu(), single
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_device_runner_virtual_ranks_on_one_gpu(hip_lib, world):
+    """The in-process multi-device runner (PP_GPUS=N behind the node) with the real MI355X backend: N rank threads sharing the
+    one GPU of the test box, each on its own stream, peer copies degenerate to same-device copies ordered by events; the
+    result must equal the single-process pipeline bit for bit."""
+    got, single = _multi_device_case([torch.device("cuda:0")] * world)
+    _assert_same_frames(got, single, True, f"{world} rank threads on one GPU")
+
+
+@pytest.mark.gpu
+def test_multi_device_runner_on_two_gpus(hip_lib):
+    """... and with one GPU per rank thread (hipMemcpyPeer over xGMI) wherever two GPUs are visible (skips on the 1-GPU gpurun box;
+    runs on the driver's multi-GPU node)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    got, single = _multi_device_case([torch.device("cuda:0"), torch.device("cuda:1")])
+    _assert_same_frames(got, single, True, "one rank thread per GPU")
+
+
+@pytest.mark.gpu
+def test_node_shards_a_long_clip_with_pp_gpus(hip_lib, monkeypatch):
+    """The drop-in itself shards (r04): the same node call with PP_GPUS=2 (virtual ranks on the one GPU of the test box) returns
+    the IMAGE / masks of the single-GPU call bit for bit; a clip of one sub-video stays on one GPU."""
+    from comfyui_propainter_nodes_amd import nodes, synth
+
+    monkeypatch.setenv("PP_ALLOW_SYNTHETIC_WEIGHTS", "1")
+    pipeline.drop_model_cache()
+    T, H, W = 9, 128, 128
+    image, mask = synth.synthetic_clip(T, H, W)
+    kw = dict(mask_dilates=2, flow_mask_dilates=3, ref_stride=2, neighbor_length=4, subvideo_length=4, raft_iter=2, fp16="enable")
+    node = nodes.ProPainterInpaint()
+    want = node.propainter_inpainting(image, mask, W, H, **kw)
+    monkeypatch.setenv("PP_GPUS", "2")
+    monkeypatch.setenv("PP_GPUS_VIRTUAL", "1")
+    cfg = pipeline.ProPainterConfig(2, 4, 4, 2, "enable", T, torch.device("cuda:0"), (W, H))
+    assert len(nodes._shard_devices(cfg, torch.device("cuda:0"))) == 2
+    got = node.propainter_inpainting(image, mask, W, H, **kw)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b.cpu())
+    out = nodes.ProPainterOutpaint().propainter_outpainting(image, W, H, 1.25, 1.0, **kw)
+    monkeypatch.delenv("PP_GPUS")
+    ref = nodes.ProPainterOutpaint().propainter_outpainting(image, W, H, 1.25, 1.0, **kw)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1].cpu(), ref[1].cpu()) and out[2:] == ref[2:]
+    monkeypatch.setenv("PP_GPUS", "8")
+    short = pipeline.ProPainterConfig(2, 4, 80, 2, "enable", T, torch.device("cuda:0"), (W, H))
+    assert len(nodes._shard_devices(short, torch.device("cuda:0"))) == 1     # one sub-video: nothing to shard
+    pipeline.drop_model_cache()
 
 @pytest.mark.gpu
 def test_bench_spawns_its_own_ranks(hip_lib):

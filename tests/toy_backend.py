@@ -40,6 +40,12 @@ class ToyBackend:
     def make_state(self, enc, flows, md, upd):
         return {"enc": enc.float(), "flows": flows, "md": md, "upd": upd}
 
+    def enc_landed(self, st, enc):
+        """The halo rows of the encoder features arrived (run_rank posts that exchange and starts the feature propagation of its
+        interior windows under it): this state holds a converted COPY, so it is refreshed; rows that were read too early would
+        have been NaN (PP_POISON_HALOS=1 in the tests)."""
+        st["enc"] = enc.float()
+
     def propagate_windows(self, st, windows):
         out = []
         for nb in windows:

@@ -22,6 +22,26 @@ CONFIGS = {
 }
 
 
+def parity(case: str, fp16: str, reps: int):
+    """Throughput AND parity of one run: the fixture's clip through OUR node method, compared with the output of the reference's
+    node method on that clip (CPU fp32, minted by tests/golden/make_golden.py)."""
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+    from node_case import evaluate_node_case
+
+    lib.load()
+    os.environ["PP_ALLOW_SYNTHETIC_WEIGHTS"] = "1"
+    best = []
+    for rep in range(reps):
+        secs = []
+        m = evaluate_node_case(case, fp16, check=False, timer=secs.append)
+        best.append(secs[0])
+    m["node_call_seconds_traced"] = round(min(best), 3)
+    m["node_call_frames_per_s_traced"] = round(m["frames"] / min(best), 2)
+    m["note"] = ("the node call of this leg keeps its stage tensors for the comparison (nodes.TRACE): the un-traced frames/s of the same "
+                 "configuration is the line printed without --parity")
+    print(json.dumps(m), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=2)
@@ -29,7 +49,12 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--size", type=str, default="")
     ap.add_argument("--virtual-ranks", type=int, default=0, help="also run the sharded driver with N in-process ranks and compare")
+    ap.add_argument("--parity", type=str, default="", help="a reference-minted node fixture (tests/golden/<name>.npz): run ITS clip through "
+                    "the node method and print PSNR / max LSB / mask + flow agreement beside the frames/s of that call")
+    ap.add_argument("--fp16", type=str, default="enable")
     a = ap.parse_args()
+    if a.parity:
+        return parity(a.parity, a.fp16, a.reps)
     c = dict(CONFIGS[a.config])
     if a.frames:
         c["T"] = a.frames
