@@ -212,7 +212,7 @@ __device__ __forceinline__ void store_quad(const ConvK& p, const EpiCtx<OT>& e, 
   OT* dst = e.out + m * p.out_ldc + c;
   if (full && quad_aligned(dst, p.out_ldc)) {
     if constexpr (sizeof(OT) == 2) {
-      h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      h4 o = {sat_half(v[0]), sat_half(v[1]), sat_half(v[2]), sat_half(v[3])};
       *reinterpret_cast<h4*>(dst) = o;
     } else {
       *reinterpret_cast<f4*>(dst) = v;
@@ -312,7 +312,7 @@ __device__ __forceinline__ void store_quad_fast(const ConvK& p, const EpiCtx<OT>
   }
   OT* dst = e.out + m * p.out_ldc + c;
   if constexpr (sizeof(OT) == 2) {
-    h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    h4 o = {sat_half(v[0]), sat_half(v[1]), sat_half(v[2]), sat_half(v[3])};
     *reinterpret_cast<h4*>(dst) = o;
   } else {
     *reinterpret_cast<f4*>(dst) = v;

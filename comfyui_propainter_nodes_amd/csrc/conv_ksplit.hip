@@ -14,7 +14,11 @@ namespace pp {
 
 constexpr int kKS = 4;  // K groups per work-group
 
-template <typename OT>
+// NST = ring stages per K group: NST - 1 chunk copies of a group in flight (3 ships).  r04 tested the hypothesis that the 13.8 us
+// of the 128 -> 128 step convolution (295 KB of weights per work-group) are the copy stream of a CU with 4 x 2 chunks of 10 KB in
+// flight: NST 4 (160 KB of LDS, 4 x 3 in flight; PP_CONV_KSPLIT_NST=4) measured 8.1 vs 7.9 ms over the 470 launches of a clip --
+// no gain, the chain is bound by its barrier-per-chunk step, not by the copies.
+template <typename OT, int NST>
 __global__ void __launch_bounds__(kKS * 256) conv_ksplit_kernel(const ConvK p) {
   typedef half_t T;
   constexpr int NT = 256;                  // threads per K group
@@ -24,7 +28,6 @@ __global__ void __launch_bounds__(kKS * 256) conv_ksplit_kernel(const ConvK p) {
   constexpr int RPP = NT / PPR;            // 64 tile rows per pass
   constexpr int WPASS = BC / RPP;          // 2
   constexpr int XWAVES = BP * PPR / 64;    // the first 2 waves' worth of lanes cover the pixel tile; the others repeat it
-  constexpr int NST = 3;
   constexpr int STAGE = (BP + BC) * LDK;   // elements per ring stage
   constexpr int NLOADS = 1 + WPASS;
 
@@ -171,13 +174,16 @@ __global__ void __launch_bounds__(kKS * 256) conv_ksplit_kernel(const ConvK p) {
 
   // this wave's copies of chunk qs have landed when at most min(NST-2, chunks after qs) later chunks are pending
   auto wait_landed = [&](int after) PP_INLINE_LAMBDA {
-    if (after <= 0) pp_wait_vmcnt<0>();
-    else pp_wait_vmcnt<NLOADS>();  // NST == 3: at most one later chunk in flight
+    static_for<NST - 1>([&](auto ci) {
+      constexpr int c = decltype(ci)::value;
+      if (after == c || (c == 0 && after < 0) || (c == NST - 2 && after > c)) pp_wait_vmcnt<c * NLOADS>();
+    });
   };
 
   // ---- pipeline: every group runs `per` steps (work-group-wide barriers), the last group may have fewer live ones ----
-  if (nst > 0) dma_stage(0);
-  if (nst > 1) dma_stage(1);
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j)
+    if (j < nst) dma_stage(j);
   wait_landed(nst - 1);
   pp_barrier();
   int st = 0;
@@ -227,13 +233,19 @@ __global__ void __launch_bounds__(kKS * 256) conv_ksplit_kernel(const ConvK p) {
       [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
 }
 
+template <typename OT, int NST>
+static int launch_ksplit_n(void* stream, const ConvK& k, int Z) {
+  constexpr size_t smem = (size_t)kKS * NST * (32 + 128) * 32 * sizeof(half_t);  // 120 KiB (NST 3) / 160 KiB (NST 4)
+  dim3 grid((unsigned)((k.M + 31) / 32), (unsigned)((k.Cout + 127) / 128), (unsigned)Z);
+  PP_ALLOW_BIG_LDS((&conv_ksplit_kernel<OT, NST>), smem);
+  PP_LAUNCH((conv_ksplit_kernel<OT, NST>), grid, dim3(kKS * 256), smem, stream, k);
+  return pp_check_launch("pp_conv2d");
+}
+
 template <typename OT>
 static int launch_ksplit_t(void* stream, const ConvK& k, int Z) {
-  constexpr size_t smem = (size_t)kKS * 3 * (32 + 128) * 32 * sizeof(half_t);  // 120 KiB
-  dim3 grid((unsigned)((k.M + 31) / 32), (unsigned)((k.Cout + 127) / 128), (unsigned)Z);
-  PP_ALLOW_BIG_LDS((&conv_ksplit_kernel<OT>), smem);
-  PP_LAUNCH((conv_ksplit_kernel<OT>), grid, dim3(kKS * 256), smem, stream, k);
-  return pp_check_launch("pp_conv2d");
+  // (same chunks in the same order per group whatever the ring depth: bit-identical results)
+  return options().ksplit_nst == 3 ? launch_ksplit_n<OT, 3>(stream, k, Z) : launch_ksplit_n<OT, 4>(stream, k, Z);
 }
 
 // returns 1 when the problem is not a small-image / long-K one (the caller uses the regular tiles).  The decision is a

@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(KS * NW * 64) deform_conv_kernel(const DeformS
         v = k10 ? t10 : v;
         const f2 t11 = v + r.w11 * f2{(float)r.q11[e], (float)r.q11[e + 1]};
         v = k11 ? t11 : v;
-        o[e] = (half_t)v[0];
-        o[e + 1] = (half_t)v[1];
+        o[e] = sat_half(v[0]);
+        o[e + 1] = sat_half(v[1]);
       }
       bf[b] = o;
     }

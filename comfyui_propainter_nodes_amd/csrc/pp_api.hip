@@ -63,6 +63,8 @@ static void load_options() {
   o.halo = tri("PP_CONV_HALO");
   o.halo_ct = tri("PP_CONV_HALO_CT") == 0 ? 0 : 1;
   o.ksplit = tri("PP_CONV_KSPLIT");
+  o.ksplit_nst = 3;
+  if (const char* e = getenv("PP_CONV_KSPLIT_NST")) o.ksplit_nst = e[0] == '4' ? 4 : 3;
   o.direct = tri("PP_CONV_DIRECT");
   o.trace = getenv("PP_CONV_TRACE") != nullptr;
   o.conv_order = 1;

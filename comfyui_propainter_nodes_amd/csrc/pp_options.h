@@ -6,6 +6,8 @@
 //   PP_CONV_HALO_CT  0           f16: the runtime-tap halo kernel everywhere; PP_F32X2: the flat kernel instead of the
 //                                compile-time-tap halo kernels (the runtime-tap PP_F32X2 halo kernel lives in tools/experiments)
 //   PP_CONV_KSPLIT   0 | force   in-work-group split-K kernel off / for every f16 problem with >= 4 chunks
+//   PP_CONV_KSPLIT_NST 3 | 4     ring stages per K group of the split-K kernel (default 3; 4 = three chunk copies per group in flight, 160 KB:
+//                                measured r04: 8.1 vs 7.9 ms on the 470 128 -> 128 step convolutions, no gain -- the chain is not copy-bound)
 //   PP_CONV_TILE     large | small | xlforce | tiny | classic   pin one flat-tile family
 //   PP_CONV_DIRECT   0 | force   <= 4-output-channel streaming kernel off / regardless of the image size
 //   PP_CONV_ORDER    launch      flat-tile kernels: work-groups in launch order (pixel tiles first) instead of XCD-contiguous,
@@ -21,6 +23,7 @@ struct Options {
   int halo;     // 0 off, 1 auto, 2 force
   int halo_ct;  // 0 runtime taps, 1 auto
   int ksplit;   // 0 off, 1 auto, 2 force
+  int ksplit_nst;  // 3 or 4
   int tile;     // 0 auto, 1 large, 2 small, 4 xlforce, 5 tiny, 6 classic
   int direct;   // 0 off, 1 auto, 2 force
   int trace;

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) deform_cols_kernel(const DeformK k) {
         if (y1ok && x1ok) acc(r11, w11);
         h8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+        for (int e = 0; e < 8; ++e) o[e] = sat_half(v[e]);
         *reinterpret_cast<h8*>(dst + c) = o;
       }
       return;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) upsample2x_h8_kernel(const half_t* __rest
   for (int e = 0; e < 8; ++e) {
     const float v = (1.f - ly) * ((1.f - lx) * (float)v00[e] + lx * (float)v01[e]) +
                     ly * ((1.f - lx) * (float)v10[e] + lx * (float)v11[e]);
-    o[e] = (half_t)v;
+    o[e] = sat_half(v);
   }
   *reinterpret_cast<h8*>(out + opix * out_ldc + pc * 8) = o;
 }
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) rfc_prep_kernel(const float* __restrict__
   const int to = d ? (T - 1 - t) : t;
   OT* o = out + (((int64_t)to * 2 + d) * HW + p) * 4;
   if constexpr (sizeof(OT) == 2) {
-    h4 v = {(half_t)(f[0] * (1.f - m)), (half_t)(f[1] * (1.f - m)), (half_t)m, (half_t)0.f};
+    h4 v = {sat_half(f[0] * (1.f - m)), sat_half(f[1] * (1.f - m)), (half_t)m, (half_t)0.f};
     *reinterpret_cast<h4*>(o) = v;
   } else {
     *reinterpret_cast<f4*>(o) = f4{f[0] * (1.f - m), f[1] * (1.f - m), m, 0.f};

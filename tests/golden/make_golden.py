@@ -265,7 +265,7 @@ def _rel(a, b):
 
 def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_length, ref_stride, subvideo_length,
                   mask_dilates=5, flow_mask_dilates=8, width_scale=1.2, height_scale=1.0, seed=0, flow_stride=4,
-                  save=True, check_oracle=True, mask_kind="static"):
+                  save=True, check_oracle=True, mask_kind="static", weights_variant=""):
     """BASELINE-config fixtures minted THROUGH THE REFERENCE'S NODE METHODS (propainter_nodes.py:93-154 / :231-310),
     fp16 "disable" on CPU, with the stage tensors captured on the way.  Stored compactly (the inputs are regenerable
     from the seed): RAFT flows as f32 on a 2*`flow_stride` sub-grid, completed flows as f16 on a `flow_stride` sub-grid, updated masks bit-packed, the node's IMAGE output only
@@ -273,7 +273,7 @@ def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_len
     against its own host plumbing), the two mask outputs bit-packed."""
     import time
 
-    sds = weights.synth_state_dicts(seed)
+    sds = weights.synth_state_dicts(seed, weights_variant)
     ref, models = build_reference_models(sds)
     import reference.propainter_inference as PI
     import reference.propainter_nodes as RN
@@ -342,7 +342,7 @@ def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_len
             HERE / f"{name}.npz",
             kind=np.array(kind), params_json=np.array(__import__("json").dumps(dict(
                 T=T, H=H, W=W, width=width, height=height, width_scale=width_scale, height_scale=height_scale, seed=seed,
-                flow_stride=s, mask_kind=mask_kind, **common))),
+                flow_stride=s, mask_kind=mask_kind, weights_variant=weights_variant, **common))),
             gt_flow=np.stack([cap["gt"][i][0, :, :, ::2 * s, ::2 * s].numpy() for i in (0, 1)], 0).astype(np.float32),
             pred_flow=np.stack([cap["pred"][i][0, :, :, ::s, ::s].numpy() for i in (0, 1)], 0).astype(np.float16),
             updated_masks=np.packbits(cap["um"][0, :, 0].numpy().astype(np.uint8)),
@@ -386,6 +386,12 @@ NODE_CASES = {
                           ref_stride=10, subvideo_length=80, flow_stride=16),
     # an INTERIOR sub-video at real size: 170 frames of 640x360 = flow-completion sub-videos [0,80) [80,160) [160,169) and
     # image-propagation sub-videos [0,80) [80,160) [160,170): the middle one has halos on BOTH sides (propainter_inference.py:115-144, 172-212)
+    # configs[1] in full with the CONTRACTIVE weight variant (weights._synth_tensor): the flow-completion recurrence damps input
+    # perturbations instead of amplifying them (tools/diag_recurrence_sensitivity.py: 8e-4 px response to a 1.4e-4 px perturbation
+    # at 80 frames, against 3.9 px with the default set), so the completed flows can be asserted pointwise INSIDE the hole at the
+    # full temporal length, end to end
+    "cfg2_80f_contractive_node": dict(kind="inpaint", T=80, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                                      ref_stride=10, subvideo_length=80, flow_stride=8, weights_variant="contractive"),
     "cfg4_170f_node": dict(kind="inpaint", T=170, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
                            ref_stride=10, subvideo_length=80, flow_stride=8),
 }

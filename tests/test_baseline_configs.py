@@ -37,6 +37,10 @@ Tolerances (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact
   the test asserts the completed flows tightly OUTSIDE the flow mask (2e-3 px beyond the fixture's f16 storage
   rounding: they are the RAFT flows) and only
   mean < 0.25 / max < 10 px inside; masks, schedules and the final frames keep their bounds.
+  cfg2_80f_contractive_node (r04): configs[1] in full with the CONTRACTIVE synthetic-weight variant -- the recurrence damps
+  input perturbations (8e-4 px response to 1.4e-4 px at 80 frames on the MI355X, tools/diag_recurrence_sensitivity.py), so the
+  completed flows are asserted pointwise inside the hole at the full length: max < 2e-2 / mean < 2e-3 px (fp32 storage),
+  max < 0.5 / mean < 1e-2 px (f16 storage: its own rounding, 4.7e-2 px measured, is what is left).
 A live-oracle case covers configs[4]'s geometry (1280x720, nl 20: 60x107 -> 60x108 token grid, 405 pooled keys)."""
 import json
 from pathlib import Path
@@ -60,7 +64,7 @@ def synthetic_models(monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fp16", ["enable", "disable"])
 @pytest.mark.parametrize("case", ["cfg1_node", "cfg2_24f_node", "cfg3_12f_node", "cfg2_80f_node", "cfg4_100f_node", "mov_20f_node",
-                                  "cfg3_80f_node", "cfg5_90f_node", "cfg4_170f_node"])
+                                  "cfg3_80f_node", "cfg5_90f_node", "cfg4_170f_node", "cfg2_80f_contractive_node"])
 def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
     check_node_case(case, fp16)
 
