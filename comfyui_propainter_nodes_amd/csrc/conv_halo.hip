@@ -254,7 +254,12 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_ct_kernel(con
         if constexpr (tap + 2 == NTAPS) w_next_chunk();  // the iterator moves on when the look-ahead crosses the chunk end
         fetch_w(w2, (tap + 2) % NTAPS);
       }
-      if constexpr (pre_last) {
+      // the next chunk's pixels are fetched (to registers) at the last-but-one tap: one tap of MFMAs for the loads to land.
+      // (r04 measured issuing them at tap 0 instead -- NTAPS - 1 taps ahead, the counted waits adjusted for the in-order
+      //  retirement: 309.2 vs 311.4 TF/s over the family on the whole clip, inside the noise: the chunk boundary's cost is
+      //  not the latency of these loads.)
+      constexpr int XF = NTAPS - 2;
+      if constexpr (tap == XF) {
         if (next_chunk) fetch_x();
       }
       compute(tapc, w0);
@@ -267,9 +272,10 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_ct_kernel(con
         } else {
           wait_vmcnt_hidden<0>();
         }
-      } else if constexpr (pre_last) {
-        // queue: [weights q+1] [weights q+2] [pixels]: weights q+1 must have landed
-        if (next_chunk) wait_vmcnt_hidden<WPASS + NX>(); else wait_vmcnt_hidden<0>();
+      } else if constexpr (tap == XF || tap == XF + 1) {
+        // queue after tap XF: [weights q+1] [weights q+2] [pixels]; after tap XF + 1: [weights q+2] [pixels] [weights q+3]:
+        // the weights of the next step must have landed, the pixels and the newest weights may stay in flight
+        if (next_chunk) wait_vmcnt_hidden<WPASS + NX>(); else if (more_w) wait_vmcnt_hidden<WPASS>(); else wait_vmcnt_hidden<0>();
       } else {
         if (more_w) wait_vmcnt_hidden<WPASS>(); else wait_vmcnt_hidden<0>();
       }

@@ -128,10 +128,12 @@ def _expand_masks(m: torch.Tensor, T: int) -> torch.Tensor:
 def _output(comp_u8: torch.Tensor, fm_u8: torch.Tensor, md_u8: torch.Tensor):
     """handle_output (image_utils.py:276-290): IMAGE fp32 k/255 on the host, the two masks fp32 on the device.
     The uint8 frames cross PCIe (a quarter of the fp32 bytes) and become float32(k) / 255 on the host cores (the same
-    IEEE division as the reference's numpy expression); PP_OUTPUT=device (the default, r03) converts on the GPU and copies fp32 instead.
+    IEEE division as the reference's numpy expression); PP_OUTPUT=device (r03) converts on the GPU and copies fp32 instead; the r04 default
+    PP_OUTPUT=overlap does that range by range under the remaining windows (_OverlapImageSink) and only falls back to this function
+    when no page-locked buffer is available.
     (PP_OUTPUT=host selects the uint8 D2H + host conversion of this function; PP_OUTPUT=stream the same host arithmetic
     streamed under the window loop by _HostImageSink -- slower end to end on the r03 box, see _run.)"""
-    if os.environ.get("PP_OUTPUT", "device") == "device" and comp_u8.is_cuda:
+    if os.environ.get("PP_OUTPUT", "overlap") in ("device", "overlap") and comp_u8.is_cuda:
         # float32(k) / 255 on the GPU (the same IEEE division, bit-identical), then D2H through a page-locked staging buffer
         # kept between calls (a D2H into fresh pageable memory is paced by the driver's bounce buffers and the first touch
         # of 221 MB: 24 ms for the 80-frame clip) and one multi-threaded host copy into the fresh tensor ComfyUI will own
@@ -148,6 +150,49 @@ def _output(comp_u8: torch.Tensor, fm_u8: torch.Tensor, md_u8: torch.Tensor):
     else:
         images = comp_u8.cpu().to(torch.float32).div_(255.0)
     return images, fm_u8.float().squeeze(), md_u8.float().squeeze()
+
+
+class _OverlapImageSink:
+    """The node's IMAGE leaves the GPU while the remaining windows run, WITHOUT a worker thread (r04): every
+    time pipeline.run_inpainting reports a frame range that has received its last blend, the launching thread itself enqueues --
+    on a side stream, behind an event of the compute stream -- the uint8 -> fp32 k/255 conversion of that range (the same IEEE
+    division as _output) and its asynchronous copy into the page-locked staging buffer kept between calls.  No host
+    synchronisation until the single wait in finish(); what is left after the last kernel is the copy of the last range and the
+    multi-threaded host copy into the fresh tensor ComfyUI will own.  (The r02 streaming sink converted on a worker thread that
+    fought the launching thread for the interpreter: +58 ms on the pipeline, _HostImageSink.)"""
+
+    def __init__(self, T: int, H: int, W: int, device):
+        self.device = device
+        self.shape = (T, H, W, 3)
+        self.stage = _pinned_stage(self.shape)
+        self.stream = torch.cuda.Stream(device) if self.stage is not None else None
+        self.tmp = []
+
+    @property
+    def ok(self) -> bool:
+        return self.stage is not None
+
+    def frames_final(self, comp: torch.Tensor, lo: int, hi: int) -> None:
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            img = ops.image_from_u8(comp[lo:hi])
+            self.stage[lo:hi].copy_(img, non_blocking=True)
+            self.tmp.append(img)           # kept until finish(): freed tensors of a side stream must not be reused under the copy
+
+    def abandon(self) -> None:
+        if self.stream is not None:
+            self.stream.synchronize()
+            _pinned_release(self.stage)
+
+    def finish(self) -> torch.Tensor:
+        self.stream.synchronize()
+        self.tmp.clear()
+        images = torch.empty(self.shape, dtype=torch.float32)
+        images.copy_(self.stage)
+        _pinned_release(self.stage)
+        return images
 
 
 class _HostImageSink:
@@ -303,8 +348,14 @@ def _run(models, config, fr_u8, fr_f32, fm, md, tm: _Timer, static_masks=False):
     # (r03: measured on the MI355X box, node call of the 80-frame clip: PP_OUTPUT=device 452 ms, host 466 ms, stream 496 ms --
     # with the streaming sink the pipeline itself ran 58 ms longer, whichever way its worker waits for the copies;
     # tools/node_gap.py.  The default is therefore the GPU conversion + one D2H; the sink stays selectable.)
-    stream_out = fr_u8.is_cuda and os.environ.get("PP_OUTPUT", "device") == "stream" and TRACE is None
-    sink = _HostImageSink(*fr_u8.shape[:3], fr_u8.device) if stream_out else None
+    mode = os.environ.get("PP_OUTPUT", "overlap") if (fr_u8.is_cuda and TRACE is None) else "device"
+    sink = None
+    if mode == "stream":
+        sink = _HostImageSink(*fr_u8.shape[:3], fr_u8.device)
+    elif mode == "overlap":
+        sink = _OverlapImageSink(*fr_u8.shape[:3], fr_u8.device)
+        if not sink.ok:                # no page-locked buffer to be had: the plain path
+            sink = None
     try:
         comp = run_inpainting(models, fr_u8, fm, md, config, trace=TRACE, to_host=False, frames_f32=fr_f32, sink=sink,
                               static_masks=static_masks)
