@@ -55,6 +55,7 @@ struct ConvK {
   int pre_add_ldc;
   int tile_order;  // flat-tile kernels: 1 = XCD-contiguous, channel tiles of a pixel tile adjacent (flat_tile_of); 0 = launch order
   const float* weight_f32;  // optional fp32 [tap][chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
+  int flat_taps;            // weights = one (ky, kx, c)-ordered row per output channel; conv_gemm_f16.hip gathers the patches
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float param) {
@@ -434,6 +435,8 @@ int launch_halo_split(void* stream, const ConvK& k, int Z);
 int launch_halo_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // conv_gemm_f16.hip: 1x1 / stride-1 / unpadded single-segment f16 layers (plain GEMMs); returns 1 when not eligible
 int launch_gemm_f16(void* stream, const ConvK& k, int Z, bool out_f16);
+// ... its patch-gather form (pp_conv2d_params.flat_taps); PP_ERR_UNSUPPORTED when the layer is not eligible
+int launch_gemm_f16_patch(void* stream, const ConvK& k, int Z, bool out_f16);
 // conv_direct.hip: at most 4 output channels, streaming fp32-FMA kernel; returns 1 when not eligible
 int launch_direct_small_cout(void* stream, const ConvK& k, int Z, int dtype, bool out_f16);
 

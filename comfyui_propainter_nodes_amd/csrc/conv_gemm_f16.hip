@@ -25,7 +25,11 @@
 
 namespace pp {
 
-template <typename OT, int WC, int WP, int TC, int TP, int KC, int NST>
+// PATCH (pp_conv2d_params.flat_taps): the pixel operand is F.unfold(x) of a kh x kw / stride / padding patch grid, gathered on
+// the fly -- row m = output position (n, i, j), column k = (ky, kx, c); a 16-byte piece is 8 channels of ONE tap (C % 8 == 0),
+// so its source is either 8 consecutive channels of one input pixel or, outside the image, zeros.  Same chunks in the same
+// order as the GEMM over the materialised patch matrix: bit-identical to unfold + GEMM.
+template <typename OT, int WC, int WP, int TC, int TP, int KC, int NST, bool PATCH = false>
 __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK p) {
   typedef half_t T;
   constexpr int NT = WC * WP * 64;
@@ -52,12 +56,25 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
   const int pcs = pc ^ ((row0 >> 1) & 3);  // (RPP is a multiple of 16: the swizzle is the same in every pass)
   const T* xsrc[XPASS];
   const T* wsrc[WPASS];
+  int py0[XPASS], px0[XPASS];   // PATCH: input coordinates of tap (0, 0) of this thread's rows
   {
     const T* xb = reinterpret_cast<const T*>(p.in_ptr[0]);
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
       const int64_t m = p_base + row0 + i * RPP;
-      xsrc[i] = xb + (m < p.M ? m : p.M - 1) * p.in_ldc[0] + pcs * 8;  // rows past M: clamped, results never stored
+      const int64_t mm = m < p.M ? m : p.M - 1;  // rows past M: clamped, results never stored
+      if constexpr (PATCH) {
+        const int wo = (int)(mm % p.Wo);
+        const int64_t t = mm / p.Wo;
+        const int ho = (int)(t % p.Ho);
+        const int64_t n = t / p.Ho;
+        py0[i] = ho * p.sh - p.ph;
+        px0[i] = wo * p.sw - p.pw;
+        xsrc[i] = xb + n * p.H * p.W * p.in_ldc[0];   // image base; pixel and channel offsets per piece
+      } else {
+        py0[i] = px0[i] = 0;
+        xsrc[i] = xb + mm * p.in_ldc[0] + pcs * 8;
+      }
     }
     const T* wb = reinterpret_cast<const T*>(p.weight);
 #pragma unroll
@@ -66,7 +83,9 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
       wsrc[i] = wb + (int64_t)(co < p.Cout ? co : p.Cout - 1) * p.Kp + pcs * 8;
     }
   }
-  const int C = p.in_C[0];
+  const int C = PATCH ? p.in_C[0] * p.kh * p.kw : p.in_C[0];   // valid k
+  const int Cin = p.in_C[0], ldc = p.in_ldc[0];
+  const float inv_c = 1.f / (float)Cin, inv_kw = 1.f / (float)p.kw;   // (k + 0.5) * inv is exact for these small integers
   const int nchunks = p.nchunks;
   int q = 0;  // next chunk to copy
 
@@ -78,9 +97,24 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
       const int k0 = q * 32;
       const bool live = q < nchunks;                  // (a partial last stage copies zeros for its dead chunks)
       const bool xok = live && (k0 + pcs * 8 < C);    // channel tail of the last chunk (its weights are zero-padded)
+      if constexpr (PATCH) {
+        const int kk = k0 + pcs * 8;
+        const int tap = (int)(((float)kk + 0.5f) * inv_c);
+        const int c = kk - tap * Cin;
+        const int ky = (int)(((float)tap + 0.5f) * inv_kw);
+        const int kx = tap - ky * p.kw;
 #pragma unroll
-      for (int i = 0; i < XPASS; ++i)
-        glds16(xok ? static_cast<const void*>(xsrc[i] + k0) : static_cast<const void*>(pp_zero16), xt + (i * NT + wave * 64) * 8);
+        for (int i = 0; i < XPASS; ++i) {
+          const int y = py0[i] + ky * p.dh, x = px0[i] + kx * p.dw;
+          const bool in = xok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+          const T* src = xsrc[i] + ((int64_t)y * p.W + x) * ldc + c;
+          glds16(in ? static_cast<const void*>(src) : static_cast<const void*>(pp_zero16), xt + (i * NT + wave * 64) * 8);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i)
+          glds16(xok ? static_cast<const void*>(xsrc[i] + k0) : static_cast<const void*>(pp_zero16), xt + (i * NT + wave * 64) * 8);
+      }
 #pragma unroll
       for (int i = 0; i < WPASS; ++i)
         glds16(live ? static_cast<const void*>(wsrc[i] + k0) : static_cast<const void*>(pp_zero16), wt + (i * NT + wave * 64) * 8);
@@ -150,14 +184,14 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
       [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
 }
 
-template <typename OT, int WC, int WP, int TC, int TP, int KC, int NST>
+template <typename OT, int WC, int WP, int TC, int TP, int KC, int NST, bool PATCH = false>
 static int launch_gemm_cfg(void* stream, const ConvK& k) {
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;
   constexpr size_t smem = (size_t)NST * KC * (BC + BP) * 32 * sizeof(half_t);
   static_assert(smem <= 160 * 1024, "LDS of one CU");
   dim3 grid((unsigned)(((k.M + BP - 1) / BP) * ((k.Cout + BC - 1) / BC)), 1u, 1u);
-  PP_ALLOW_BIG_LDS((&conv_gemm_f16_kernel<OT, WC, WP, TC, TP, KC, NST>), smem);
-  PP_LAUNCH((conv_gemm_f16_kernel<OT, WC, WP, TC, TP, KC, NST>), grid, dim3(WC * WP * 64), smem, stream, k);
+  PP_ALLOW_BIG_LDS((&conv_gemm_f16_kernel<OT, WC, WP, TC, TP, KC, NST, PATCH>), smem);
+  PP_LAUNCH((conv_gemm_f16_kernel<OT, WC, WP, TC, TP, KC, NST, PATCH>), grid, dim3(WC * WP * 64), smem, stream, k);
   return pp_check_launch("pp_conv2d");
 }
 
@@ -197,6 +231,17 @@ int launch_gemm_f16(void* stream, const ConvK& k, int Z, bool out_f16) {
     if (blocks128 < 512 || k.Cout < 96) return 1;
   }
   return out_f16 ? launch_gemm_t<half_t>(stream, k, o.gemm_cfg) : launch_gemm_t<float>(stream, k, o.gemm_cfg);
+}
+
+
+// pp_conv2d_params.flat_taps: conv(x) == linear(unfold(x)) with the patches gathered inside the GEMM kernel
+int launch_gemm_f16_patch(void* stream, const ConvK& k, int Z, bool out_f16) {
+  if (Z != 1 || k.nseg != 1 || (k.in_C[0] & 7) || k.pad_mode == PP_PAD_REPLICATE)
+    return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: flat_taps needs one f16 segment with C % 8 == 0, zero padding, Z 1");
+  if (options().trace) fprintf(stderr, "pp_conv2d: GEMM kernel, patch gather %dx%d s%d, C %d, M %lld, Cout %d\n", k.kh, k.kw, k.sh, k.in_C[0], (long long)k.M, k.Cout);
+  const bool wide = (k.Cout + 255) / 256 * 256 - k.Cout <= k.Cout / 8;
+  if (wide) return out_f16 ? launch_gemm_cfg<half_t, 4, 2, 4, 4, 1, 3, true>(stream, k) : launch_gemm_cfg<float, 4, 2, 4, 4, 1, 3, true>(stream, k);
+  return out_f16 ? launch_gemm_cfg<half_t, 2, 4, 4, 4, 1, 3, true>(stream, k) : launch_gemm_cfg<float, 2, 4, 4, 4, 1, 3, true>(stream, k);
 }
 
 }  // namespace pp

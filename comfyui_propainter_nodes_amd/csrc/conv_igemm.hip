@@ -57,6 +57,12 @@ int convk_from_params(const pp_conv2d_params* p, ConvK* kp, const char* who, boo
   k.weight = p->weight; k.w_zoff = p->w_zoff;
   k.chunks_per_tap = cpt;
   k.nchunks = cpt * k.kh * k.kw;
+  k.flat_taps = p->flat_taps != 0;
+  if (k.flat_taps) {  // one (ky, kx, c)-ordered weight row per output channel, padded to 32 at the end only
+    if (p->dtype != PP_F16 || p->nseg != 1 || p->Z != 1 || p->pad_mode == PP_PAD_REPLICATE)
+      return fail2(PP_ERR_UNSUPPORTED, who, "flat_taps: f16, one segment, Z 1, zero padding only");
+    k.nchunks = (int)(((int64_t)k.kh * k.kw * p->in_C[0] + 31) / 32);
+  }
   k.Kp = k.nchunks * 32;
   k.bias = reinterpret_cast<const float*>(p->bias); k.bias_zoff = p->bias_zoff;
   k.Cout = (int)p->Cout;
@@ -86,11 +92,13 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   const int bad = convk_from_params(p, &k, "pp_conv2d", false);
   if (bad != PP_OK) return bad;
   const int Z = (int)p->Z;
-  if (k.Cout <= 4) {  // 2-3 output channels on a 32-channel MFMA tile are wasted matrix work: streaming vector-ALU kernel
+  if (k.flat_taps && p->dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: flat_taps needs PP_F16");
+  if (k.Cout <= 4 && !k.flat_taps) {  // 2-3 output channels on a 32-channel MFMA tile are wasted matrix work: streaming vector-ALU kernel
     const int rd = launch_direct_small_cout(stream, k, Z, p->dtype, p->out_dtype == PP_F16);
     if (rd != 1) return rd;
   }
   if (p->dtype == PP_F16) {
+    if (k.flat_taps) return launch_gemm_f16_patch(stream, k, Z, p->out_dtype == PP_F16);
     const int rc = launch_ksplit_f16(stream, k, Z, p->out_dtype == PP_F16);  // small M, long K: in-work-group split K
     if (rc != 1) return rc;
     const int rh = launch_halo_f16(stream, k, Z, p->out_dtype == PP_F16);  // stride-1 multi-tap: pixel tile + halo staged once per chunk

@@ -13,6 +13,7 @@ Scheduling decisions (all numerically equivalent re-orderings of the reference):
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -278,7 +279,8 @@ class InpaintGeneratorMI355:
         att = torch.empty(t, fh, fw, 512, device=dev, dtype=self.dt)
         y = torch.empty(t, fh, fw, 512, device=dev, dtype=self.dt)
         f1 = torch.empty(t, fh, fw, 1960, device=dev, dtype=self.dt)
-        f2 = torch.empty(t, fh, fw, 1960, device=dev, dtype=self.dt)
+        fused_fc2 = self.dt == torch.float16 and os.environ.get("PP_FC2_UNFOLD", "fused") != "copy"
+        f2 = None if fused_fc2 else torch.empty(t, fh, fw, 1960, device=dev, dtype=self.dt)
         folded = torch.empty(t, h, w, 40, device=dev, dtype=self.dt)
         tok2 = torch.empty_like(tok)
         t_inds = [torch.arange(i, t, 2, dtype=torch.int32, device=dev) for i in (0, 1)]
@@ -291,9 +293,13 @@ class InpaintGeneratorMI355:
             ops.conv2d(B["proj"], [att], tok2, epi="add", aux1=tok)
             ops.layernorm(tok2, y, B["n2w"], B["n2b"])
             ops.conv2d(B["fc1"], [y], f1)
-            ops.fold(f1.view(t, fh * fw, 1960), folded, fh, fw, True)
-            ops.unfold_gelu(folded, f2.view(t, fh * fw, 1960), fh, fw)
-            ops.conv2d(B["fc2"], [f2], tok, epi="add", aux1=tok2)
+            # (r04: the GELU once per folded value in pp_fold instead of on each of its <= 9 unfolded copies: bit-identical)
+            ops.fold(f1.view(t, fh * fw, 1960), folded, fh, fw, True, gelu=True)
+            if fused_fc2:   # fc2 gathers its 7x7 / stride-3 patches from the 40-channel map itself: no 49x unfolded copy
+                ops.linear_of_unfold(B["fc2"], folded, tok, 7, 3, 3, epi="add", aux1=tok2)
+            else:
+                ops.unfold_gelu(folded, f2.view(t, fh * fw, 1960), fh, fw, pre_activated=True)
+                ops.conv2d(B["fc2"], [f2], tok, epi="add", aux1=tok2)
         return tok
 
     def window_mask_flags(self, st: ClipState, nb: list[int]) -> torch.Tensor:

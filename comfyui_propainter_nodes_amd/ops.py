@@ -367,6 +367,43 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, aux
     return out
 
 
+def linear_of_unfold(spec: ConvSpec, x: torch.Tensor, out: torch.Tensor, kernel: int, stride: int, padding: int, *,
+                     aux1=None, **kw) -> torch.Tensor:
+    """out = linear(unfold(x)) WITHOUT the unfolded matrix (r04, pp_conv2d_params.flat_taps): `spec` is the Linear over the
+    tap-major patch vectors (a 1x1 ConvSpec with kernel*kernel*C input channels), x f16 [N,H,W,C] (C % 8 == 0) the map the
+    patches are taken from, out [N, ho, wo, Cout].  Bit-identical to conv2d(spec, [unfold(x)], out): same chunks, same order
+    (the FusionFeedForward's fc2 reads the folded 40-channel map instead of a 49x copy, sparse_transformer.py:413-433)."""
+    n, h, w, c, ldc = nhwc_view(x)
+    if spec.kh != 1 or spec.kw != 1 or spec.groups != 1 or len(spec.seg_channels) != 1 or spec.split or x.dtype != torch.float16:
+        raise ValueError("linear_of_unfold: needs an f16 single-segment Linear spec")
+    if spec.cin_valid != kernel * kernel * c or c % 8:
+        raise ValueError(f"linear_of_unfold: the Linear expects {spec.cin_valid} inputs, the patches hold {kernel * kernel * c}")
+    ho, wo = (h + 2 * padding - kernel) // stride + 1, (w + 2 * padding - kernel) // stride + 1
+    on, oh, ow, oc, oldc = nhwc_view(out)
+    if (on, oh, ow) != (n, ho, wo) or oc < spec.cout:
+        raise ValueError(f"linear_of_unfold: bad output view {tuple(out.shape)} for {(n, ho, wo, spec.cout)}")
+    # the parameter block of the plain Linear on a stand-in of the patch matrix's shape, then the patch geometry
+    meta = torch.empty(n, ho, wo, spec.seg_channels[0], device="meta", dtype=x.dtype)
+    check_device(x)
+    P = _conv2d_params(spec, [meta], out, aux1=aux1, virtual_input=True, **kw)
+    P.in_ptr[0] = x.data_ptr()
+    P.in_C[0], P.in_ldc[0] = c, ldc
+    P.H, P.W = h, w
+    P.kh = P.kw = kernel
+    P.sh = P.sw = stride
+    P.ph = P.pw = padding
+    P.flat_taps = 1
+    L = _lib.current()
+    if CONV_PROFILE is not None and out.is_cuda:
+        flops = 2.0 * n * ho * wo * spec.cout * spec.cin_valid
+        key = "f16" + (f"|unfold{kernel}x{kernel}s{stride} cin{c} cout{spec.cout} g1 M{n * ho * wo}" if CONV_PROFILE.detailed else "")
+        nbytes = (x.numel() + spec.weight.numel() + n * ho * wo * spec.cout * (2 if aux1 is not None else 1)) * 2.0
+        CONV_PROFILE.launch(key, flops, lambda: L.call("pp_conv2d", stream_handle(out), P), nbytes)
+    else:
+        L.call("pp_conv2d", stream_handle(out), P)
+    return out
+
+
 def split_pack(b: torch.Tensor) -> torch.Tensor:
     """fp32 [..., K] (K % 32 == 0, dense) -> the PP_F32X2 weight packing of the same shape (an f32-typed bit container)."""
     check_device(b)
@@ -832,8 +869,9 @@ def window_attention(qkv: torch.Tensor, pkv: torch.Tensor, win_masked: torch.Ten
     return out
 
 
-def fold(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int, normalize: bool) -> torch.Tensor:
-    """x f16 [T, fh*fw, 49*C] (tap-major) -> out f16 [T,H,W,C] overlap-add (optionally averaged)."""
+def fold(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int, normalize: bool, gelu: bool = False) -> torch.Tensor:
+    """x f16 [T, fh*fw, 49*C] (tap-major) -> out f16 [T,H,W,C] overlap-add (optionally averaged; `gelu`: followed by the
+    exact GELU on the storage-rounded value, for unfold_gelu(..., pre_activated=True))."""
     check_device(x, out)
     t, h, w, c = out.shape
     if not (x.is_contiguous() and out.is_contiguous()) or tuple(x.shape) != (t, fh * fw, 49 * c):
@@ -844,12 +882,14 @@ def fold(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int, normalize: bool) 
         raise TypeError("fold: x and out must share a dtype")
     P.dtype = dtype_code(x.dtype)
     P.out, P.T, P.H, P.W, P.C, P.fh, P.fw, P.normalize = out.data_ptr(), t, h, w, c, fh, fw, int(normalize)
+    P.gelu = int(gelu)
     _call("pp_fold", out, P)
     return out
 
 
-def unfold_gelu(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int) -> torch.Tensor:
-    """x f16 [T,H,W,C] -> out f16 [T, fh*fw, 49*C] (tap-major) with exact GELU applied."""
+def unfold_gelu(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int, pre_activated: bool = False) -> torch.Tensor:
+    """x f16 [T,H,W,C] -> out f16 [T, fh*fw, 49*C] (tap-major) with exact GELU applied (`pre_activated`: x already holds
+    GELU(value) -- fold(..., gelu=True) -- and is only re-extracted)."""
     check_device(x, out)
     t, h, w, c = x.shape
     if not (x.is_contiguous() and out.is_contiguous()) or tuple(out.shape) != (t, fh * fw, 49 * c):
@@ -860,6 +900,7 @@ def unfold_gelu(x: torch.Tensor, out: torch.Tensor, fh: int, fw: int) -> torch.T
         raise TypeError("unfold_gelu: x and out must share a dtype")
     P.dtype = dtype_code(x.dtype)
     P.out, P.T, P.H, P.W, P.C, P.fh, P.fw = out.data_ptr(), t, h, w, c, fh, fw
+    P.pre_activated = int(pre_activated)
     _call("pp_unfold_gelu", out, P)
     return out
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 7
+#define PP_ABI_VERSION 8
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -135,6 +135,12 @@ typedef struct {
                              [tap][32-channel chunk][Cout padded to 2 or 4][32] for the vector-ALU kernel of the 2-3
                              channel layers (conv_direct.hip reads them through the scalar cache instead of decoding
                              `weight` into LDS per work-group); NULL = decode from `weight` */
+  int32_t flat_taps; /* (ABI v8, PP_F16, nseg 1, in_C % 8 == 0) != 0: the weights are ONE row of kh*kw*in_C channels per
+                        output channel in (ky, kx, c) order, zero-padded to a multiple of 32 at the END only -- the Linear
+                        that consumes F.unfold()'s tap-major patch vectors -- and the kernel gathers the patches itself:
+                        conv(x) == linear(unfold(x)) without the unfolded matrix (sparse_transformer.py:413-433: fc2 of the
+                        fusion feed-forward reads the folded 40-channel map, 7x7 / stride 3, instead of a 49x copy) */
+  int32_t reserved0;
 } pp_conv2d_params;
 
 int32_t pp_conv2d(void* stream, const pp_conv2d_params* p);
@@ -477,6 +483,9 @@ int32_t pp_window_attention(void* stream, const pp_window_attention_params* p);
  * weights accordingly).  pp_fold: out[t][y][x][c] = sum of the overlapping taps, divided by the
  * overlap count when `normalize` (the constant "fold of ones" map of :88-101).
  * pp_unfold_gelu: re-extract the patches and apply the exact (erf) GELU of fc2 (:83).
+ * ABI v8: the GELU may be applied by pp_fold instead (`gelu` != 0: once per folded value, after the value has been rounded
+ * to the storage type -- the number pp_unfold_gelu would read back) and pp_unfold_gelu told so (`pre_activated` != 0: it
+ * then only copies).  Bit-identical to fold + unfold_gelu; 5x fewer erf evaluations.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const void* in; /* f16 [T][fh*fw][49*C] */
@@ -484,6 +493,7 @@ typedef struct {
   int64_t T, H, W, C, fh, fw;
   int32_t normalize;
   int32_t dtype; /* in and out: PP_F16 or PP_F32 */
+  int32_t gelu;  /* (v8) != 0: exact GELU on the (normalised, storage-rounded) result */
 } pp_fold_params;
 int32_t pp_fold(void* stream, const pp_fold_params* p);
 
@@ -492,6 +502,7 @@ typedef struct {
   void* out;      /* f16 [T][fh*fw][49*C] */
   int64_t T, H, W, C, fh, fw;
   int32_t dtype; /* in and out: PP_F16 or PP_F32 */
+  int32_t pre_activated; /* (v8) != 0: `in` already holds GELU(x) (pp_fold with `gelu`): copy only */
 } pp_unfold_gelu_params;
 int32_t pp_unfold_gelu(void* stream, const pp_unfold_gelu_params* p);
 

@@ -245,6 +245,35 @@ def test_gemm_kernel_equals_flat_kernel(backend, cfg, pp_knobs):
         assert (outs[1].double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
 
 
+def test_linear_of_unfold_equals_unfold_then_linear(backend, pp_knobs):
+    """r04 (ABI v8, pp_conv2d_params.flat_taps): the Linear over F.unfold()'s tap-major patch vectors with the patches gathered
+    inside the GEMM kernel must equal unfold (a copy) + the same Linear BIT FOR BIT -- the FusionFeedForward's fc2 on the folded
+    40-channel map (7x7 / stride 3 / padding 3: patches that hang over every image border, K = 1960 with a partial last chunk),
+    wide and narrow output tiles, fp32 output, and a residual epilogue.  (The comparison Linear is pinned to the flat / GEMM
+    kernels, which walk the chunks in order like the patch kernel does; the split-K kernel these tiny problems would select sums
+    in four groups.)"""
+    pp_knobs(PP_CONV_KSPLIT="0")
+    g = torch.Generator().manual_seed(51)
+    for N, H, W, C, Cout, odt in ((2, 13, 17, 40, 264, torch.float16), (1, 9, 22, 40, 100, torch.float32), (3, 7, 7, 16, 520, torch.float16)):
+        fh, fw = (H + 6 - 7) // 3 + 1, (W + 6 - 7) // 3 + 1
+        x = torch.randn(N, H, W, C, generator=g).half().to(backend)
+        wgt = torch.randn(Cout, 49 * C, 1, 1, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        res = torch.randn(N, fh, fw, Cout, generator=g).to(odt).to(backend)
+        spec = ops.make_conv_spec(wgt, b, torch.float16).to(backend)
+        un = torch.empty(N, fh * fw, 49 * C, dtype=torch.float16, device=backend)
+        ops.unfold_gelu(x, un, fh, fw, pre_activated=True)          # tap-major patch matrix (copy only)
+        want = torch.full((N, fh, fw, Cout), float("nan"), device=backend, dtype=odt)
+        ops.conv2d(spec, [un.view(N, fh, fw, 49 * C)], want, epi="add", aux1=res)
+        got = torch.full((N, fh, fw, Cout), float("nan"), device=backend, dtype=odt)
+        ops.linear_of_unfold(spec, x, got, 7, 3, 3, epi="add", aux1=res)
+        assert torch.equal(got.cpu(), want.cpu()), (N, H, W, C, Cout, (got.float() - want.float()).abs().max())
+        ref = F.unfold(x.cpu().float().permute(0, 3, 1, 2), kernel_size=7, stride=3, padding=3)          # [N, C*49, L], c-major
+        ref = ref.view(N, C, 49, fh * fw).permute(0, 3, 2, 1).reshape(N, fh * fw, 49 * C).double()      # tap-major
+        ref = (ref @ wgt.half().double().view(Cout, -1).t() + b.double()).view(N, fh, fw, Cout) + res.cpu().double()
+        assert (got.cpu().double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("halo", ["0", "force"])
 def test_epilogue_from_a_channel(backend, halo, pp_knobs):
     """`epi_from` (ABI v6): RAFT's GRU computes the z and r gates (update.py:41-43) in ONE 256-channel PP_F32X2 convolution

@@ -71,6 +71,16 @@ def test_fold_unfold_roundtrip_against_torch(backend, dt):
     ref = F.gelu(F.unfold(x.float().permute(0, 3, 1, 2), kernel_size=7, stride=3, padding=3)).permute(0, 2, 1)
     ref = ref.view(T, fh * fw, C, 49).permute(0, 1, 3, 2).reshape(T, fh * fw, 49 * C)
     _close(un, ref)
+    # r04 (ABI v8): the GELU once per folded value in pp_fold + a copy-only unfold must equal fold + unfold_gelu BIT FOR BIT
+    # (the fused-feed-forward path of the generator, sparse_transformer.py:413-433)
+    folded, folded_g = (torch.empty(T, h, w, C, dtype=dt, device=dev) for _ in range(2))
+    ops.fold(tap_major.to(dev), folded, fh, fw, True)
+    two_step = torch.empty(T, fh * fw, 49 * C, dtype=dt, device=dev)
+    ops.unfold_gelu(folded, two_step, fh, fw)
+    ops.fold(tap_major.to(dev), folded_g, fh, fw, True, gelu=True)
+    fused = torch.empty(T, fh * fw, 49 * C, dtype=dt, device=dev)
+    ops.unfold_gelu(folded_g, fused, fh, fw, pre_activated=True)
+    assert torch.equal(fused.cpu(), two_step.cpu())
 
 
 @pytest.mark.parametrize("fh,fw,t,lt,dt", [(11, 12, 4, 3, H16), (5, 18, 4, 3, H16), (30, 54, 18, 11, H16), (15, 27, 7, 5, H16),
