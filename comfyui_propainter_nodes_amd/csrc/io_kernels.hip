@@ -8,7 +8,7 @@
 
 namespace pp {
 
-static inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
+static inline unsigned nblk(int64_t total) { return pp_blocks_1d(total); }  // (records a >= 2^32-thread launch: pp_host.h)
 
 // convert_image_to_frames (image_utils.py:106-116): u8 = trunc(clip(v*255, 0, 255)); to_tensors + "*2-1"
 // (:178-191): f = (u8/255)*2 - 1 as separate fp32 operations (the build disables FMA contraction).  The frame is

@@ -18,7 +18,23 @@ int pp_fail(int code, const char* msg) {
   return code;
 }
 
+static thread_local bool g_grid_overflow = false;
+
+unsigned pp_blocks_1d(int64_t total) {
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks * 256 >= ((int64_t)1 << 32)) g_grid_overflow = true;
+  return (unsigned)blocks;
+}
+
 int pp_check_launch(const char* what) {
+  if (g_grid_overflow) {
+    g_grid_overflow = false;
+    snprintf(g_err, sizeof(g_err), "%s: the launch needs 2^32 threads or more (HIP truncates such a grid): tensor too large for this kernel", what);
+#ifndef PP_EMU
+    (void)hipGetLastError();
+#endif
+    return PP_ERR_UNSUPPORTED;
+  }
 #ifndef PP_EMU
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -11,7 +11,7 @@
 
 namespace pp {
 
-static inline unsigned nblk2(int64_t total) { return (unsigned)((total + 255) / 256); }
+static inline unsigned nblk2(int64_t total) { return pp_blocks_1d(total); }  // (records a >= 2^32-thread launch: pp_host.h)
 
 __device__ __forceinline__ float warp_coord(int pos, float f, int size) {
   const float g = (float)pos + f;

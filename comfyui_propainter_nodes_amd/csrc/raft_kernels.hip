@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) convex_upsample_kernel(const float* __res
   out[o + 1] = uy / den;
 }
 
-static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+static inline unsigned blocks_for(int64_t total) { return pp_blocks_1d(total); }  // (records a >= 2^32-thread launch: pp_host.h)
 
 }  // namespace pp
 

@@ -7,7 +7,7 @@
 
 namespace pp {
 
-static inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
+static inline unsigned nblk(int64_t total) { return pp_blocks_1d(total); }  // (records a >= 2^32-thread launch: pp_host.h)
 
 // ----------------------------------------------------------------------------------------
 // deformable-conv column sampling: one thread per (pixel, tap k, deformable group g)
@@ -141,9 +141,12 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const T* __restrict__ i
   out[opix * out_ldc + c] = from_f32<T>(v);
 }
 
-// 8 channels per thread (f16, C % 8 == 0): 16-byte loads / stores
-__global__ void __launch_bounds__(256) upsample2x_h8_kernel(const half_t* __restrict__ in, int in_ldc,
-                                                            half_t* __restrict__ out, int out_ldc, int H, int W,
+// 8 channels per thread (C % 8 == 0): 16-byte loads / stores.  (r04: also the fp32-storage tensors -- the per-element form needs
+// one thread per element, 4.7e9 for flow completion's last upsample at 160 images of 720x1280x32, and HIP truncates a launch of
+// 2^32 threads or more: pp_host.h, pp_blocks_1d.)
+template <typename T>
+__global__ void __launch_bounds__(256) upsample2x_h8_kernel(const T* __restrict__ in, int in_ldc,
+                                                            T* __restrict__ out, int out_ldc, int H, int W,
                                                             int C, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over N*2H*2W*(C/8)
   if (idx >= total) return;
@@ -161,19 +164,16 @@ __global__ void __launch_bounds__(256) upsample2x_h8_kernel(const half_t* __rest
   const int y0 = (int)fy, x0 = (int)fx;
   const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
   const float ly = fy - (float)y0, lx = fx - (float)x0;
-  const half_t* base = in + n * (int64_t)H * W * in_ldc + pc * 8;
-  const h8 v00 = *reinterpret_cast<const h8*>(base + ((int64_t)y0 * W + x0) * in_ldc);
-  const h8 v01 = *reinterpret_cast<const h8*>(base + ((int64_t)y0 * W + x1) * in_ldc);
-  const h8 v10 = *reinterpret_cast<const h8*>(base + ((int64_t)y1 * W + x0) * in_ldc);
-  const h8 v11 = *reinterpret_cast<const h8*>(base + ((int64_t)y1 * W + x1) * in_ldc);
-  h8 o;
+  const T* base = in + n * (int64_t)H * W * in_ldc + pc * 8;
+  float v00[8], v01[8], v10[8], v11[8], o[8];
+  ld8(base + ((int64_t)y0 * W + x0) * in_ldc, v00);
+  ld8(base + ((int64_t)y0 * W + x1) * in_ldc, v01);
+  ld8(base + ((int64_t)y1 * W + x0) * in_ldc, v10);
+  ld8(base + ((int64_t)y1 * W + x1) * in_ldc, v11);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float v = (1.f - ly) * ((1.f - lx) * (float)v00[e] + lx * (float)v01[e]) +
-                    ly * ((1.f - lx) * (float)v10[e] + lx * (float)v11[e]);
-    o[e] = sat_half(v);
-  }
-  *reinterpret_cast<h8*>(out + opix * out_ldc + pc * 8) = o;
+  for (int e = 0; e < 8; ++e)
+    o[e] = (1.f - ly) * ((1.f - lx) * v00[e] + lx * v01[e]) + ly * ((1.f - lx) * v10[e] + lx * v11[e]);
+  st8(out + opix * out_ldc + pc * 8, o);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -253,11 +253,16 @@ extern "C" int32_t pp_upsample2x(void* stream, const pp_upsample2x_params* p) {
   if (!p || !p->in || !p->out) return pp_fail(PP_ERR_BAD_ARG, "pp_upsample2x: null argument");
   const int64_t total = p->N * 4 * p->H * p->W * p->C;
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_upsample2x: empty problem");
-  if (p->dtype == PP_F16 && (p->C % 8) == 0 && (p->in_ldc % 8) == 0 && (p->out_ldc % 8) == 0 &&
-      ((reinterpret_cast<uintptr_t>(p->in) | reinterpret_cast<uintptr_t>(p->out)) & 15) == 0) {
+  const bool vec8 = (p->C % 8) == 0 && (p->in_ldc % 8) == 0 && (p->out_ldc % 8) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(p->in) | reinterpret_cast<uintptr_t>(p->out)) & 15) == 0;
+  if (p->dtype == PP_F16 && vec8) {
     const int64_t tv = total / 8;
-    PP_LAUNCH(upsample2x_h8_kernel, dim3(nblk(tv)), dim3(256), 0, stream, (const half_t*)p->in, (int)p->in_ldc,
+    PP_LAUNCH((upsample2x_h8_kernel<half_t>), dim3(nblk(tv)), dim3(256), 0, stream, (const half_t*)p->in, (int)p->in_ldc,
               (half_t*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, tv);
+  } else if (p->dtype == PP_F32 && vec8) {
+    const int64_t tv = total / 8;
+    PP_LAUNCH((upsample2x_h8_kernel<float>), dim3(nblk(tv)), dim3(256), 0, stream, (const float*)p->in, (int)p->in_ldc,
+              (float*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, tv);
   } else if (p->dtype == PP_F16) {
     PP_LAUNCH((upsample2x_kernel<half_t>), dim3(nblk(total)), dim3(256), 0, stream, (const half_t*)p->in,
               (int)p->in_ldc, (half_t*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, total);

@@ -6,7 +6,7 @@
 
 namespace pp {
 
-static inline unsigned nblk3(int64_t total) { return (unsigned)((total + 255) / 256); }
+static inline unsigned nblk3(int64_t total) { return pp_blocks_1d(total); }  // (records a >= 2^32-thread launch: pp_host.h)
 
 // ----------------------------------------------------------------------------------------
 // LayerNorm: one wave per token, 8 channels per lane (C = 512)

@@ -162,3 +162,27 @@ def test_deform_conv_hand_computed_samples(backend):
     for (y, xq, *_rest) in cases:
         untouched[y, xq] = False
     assert torch.allclose(ref[untouched], x[0, :, :, ci][untouched]) and torch.allclose(got[untouched], x[0, :, :, ci][untouched])
+
+
+@pytest.mark.gpu
+def test_upsample2x_beyond_2_to_32_elements(hip_lib):
+    """r04 regression (found by the cfg5_90f_node fixture, fp16 "disable"): HIP launches a grid as a 32-bit global size and silently
+    TRUNCATES a launch of 2^32 threads or more.  The per-element fp32 upsample of flow completion's decoder -- 160 images of
+    720x1280x32 = 4.7e9 outputs -- wrote only its first 14.6 images (completed flows 30 px off from frame 7 on).  The fp32 tensors
+    now take the 8-channels-per-thread kernel; a launch that would still exceed the limit FAILS instead of returning garbage."""
+    dev = torch.device("cuda:0")
+    N, h, w, C = 160, 360, 640, 32                      # the tensor of the bug: 4.7e9 output elements (18.9 GB)
+    x = torch.randn(2, h, w, C, device=dev).repeat(N // 2, 1, 1, 1).contiguous()   # images repeat with period 2
+    out = torch.empty(N, 2 * h, 2 * w, C, device=dev)
+    ops.upsample2x(x, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out[N - 2], out[0]) and torch.equal(out[N - 1], out[1])      # the LAST images were written, and right
+    ref = torch.nn.functional.interpolate(x[:1].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+    assert (out[0] - ref[0].permute(1, 2, 0)).abs().max().item() < 1e-5
+    del out, x
+    # the per-element kernel (C % 8 != 0) on 2^32 outputs: refused
+    big = torch.empty(1, 32768, 32768, 4, device=dev)                                # 2^32 outputs (17 GB)
+    src = torch.zeros(1, 16384, 16384, 4, device=dev)
+    with pytest.raises(RuntimeError) as e:
+        ops.upsample2x(src, big)
+    assert "2^32" in str(e.value)
