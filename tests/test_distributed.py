@@ -344,7 +344,20 @@ def test_node_shards_a_long_clip_with_pp_gpus(hip_lib, monkeypatch):
     out = nodes.ProPainterOutpaint().propainter_outpainting(image, W, H, 1.25, 1.0, **kw)
     monkeypatch.delenv("PP_GPUS")
     ref = nodes.ProPainterOutpaint().propainter_outpainting(image, W, H, 1.25, 1.0, **kw)
-    assert torch.equal(out[0], ref[0]) and torch.equal(out[1].cpu(), ref[1].cpu()) and out[2:] == ref[2:]
+    assert out[2:] == ref[2:] and torch.equal(out[1].cpu(), ref[1].cpu())
+    if not torch.equal(out[0], ref[0]):     # diagnostic: which of the two paths is unstable?
+        d = (out[0] - ref[0]).abs()
+        ref2 = nodes.ProPainterOutpaint().propainter_outpainting(image, W, H, 1.25, 1.0, **kw)
+        monkeypatch.setenv("PP_GPUS", "2")
+        out2 = nodes.ProPainterOutpaint().propainter_outpainting(image, W, H, 1.25, 1.0, **kw)
+        monkeypatch.setenv("PP_OUTPUT", "device")
+        monkeypatch.delenv("PP_GPUS")
+        ref3 = nodes.ProPainterOutpaint().propainter_outpainting(image, W, H, 1.25, 1.0, **kw)
+        raise AssertionError(("outpaint IMAGE differs", float(d.max()) * 255, float((d > 0).float().mean()),
+                              [round(float(v) * 255, 1) for v in d.flatten(1).max(1).values.tolist()],
+                              "single again == single", bool(torch.equal(ref2[0], ref[0])), "sharded again == sharded",
+                              bool(torch.equal(out2[0], out[0])), "single(PP_OUTPUT=device) == single", bool(torch.equal(ref3[0], ref[0])),
+                              "single(device) == sharded", bool(torch.equal(ref3[0], out[0]))))
     monkeypatch.setenv("PP_GPUS", "8")
     short = pipeline.ProPainterConfig(2, 4, 80, 2, "enable", T, torch.device("cuda:0"), (W, H))
     assert len(nodes._shard_devices(short, torch.device("cuda:0"))) == 1     # one sub-video: nothing to shard
