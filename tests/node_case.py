@@ -136,7 +136,9 @@ def evaluate_node_case(case, fp16, check=False, timer=None):
     assert e_gt < 2e-3
     assert e_out < 2e-3                              # = the RAFT-flow bound, beyond the fixture's f16 storage rounding
     if variant == "contractive":                     # a contractive recurrence: tight at ANY length, inside the hole too
-        assert (e_pf < 2e-2 and m_pf < 2e-3) if fp16 == "disable" else (e_pf < 0.5 and m_pf < 1e-2)
+        # measured on the MI355X: fp32 storage 1.56e-2 max / 1.9e-3 mean -- that IS the fixture's f16 storage of flows of up to
+        # 36 px (half an ulp = 1.8e-2) --, f16 storage 4.7e-2 / 2.2e-3
+        assert (e_pf < 2.5e-2 and m_pf < 3e-3) if fp16 == "disable" else (e_pf < 0.15 and m_pf < 5e-3)
     elif T > 40:                                     # chaotic inside the hole (see the module docstring)
         assert m_pf < 0.25 and e_pf < 10.0
     elif fp16 == "disable":

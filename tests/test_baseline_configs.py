@@ -39,8 +39,9 @@ Tolerances (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact
   mean < 0.25 / max < 10 px inside; masks, schedules and the final frames keep their bounds.
   cfg2_80f_contractive_node (r04): configs[1] in full with the CONTRACTIVE synthetic-weight variant -- the recurrence damps
   input perturbations (8e-4 px response to 1.4e-4 px at 80 frames on the MI355X, tools/diag_recurrence_sensitivity.py), so the
-  completed flows are asserted pointwise inside the hole at the full length: max < 2e-2 / mean < 2e-3 px (fp32 storage),
-  max < 0.5 / mean < 1e-2 px (f16 storage: its own rounding, 4.7e-2 px measured, is what is left).
+  completed flows are asserted pointwise inside the hole at the full length: max < 2.5e-2 / mean < 3e-3 px (fp32 storage; measured
+  1.56e-2 / 1.9e-3 = the fixture's own f16 storage of flows of up to 36 px), max < 0.15 / mean < 5e-3 px (f16 storage: measured
+  4.7e-2 / 2.2e-3); final frames 58.1 / 77.4 dB, max 1 LSB.
 A live-oracle case covers configs[4]'s geometry (1280x720, nl 20: 60x107 -> 60x108 token grid, 405 pooled keys)."""
 import json
 from pathlib import Path
