@@ -103,7 +103,16 @@ __device__ __forceinline__ void wait_vmcnt_hidden() {
 __device__ __forceinline__ void pp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // the instruction scheduler moves nothing across this point (emits no code)
 __device__ __forceinline__ void pp_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Work-group barrier that does NOT drain the vector-memory queue (LDS-DMA copies stay in flight across it) but DOES retire this
+// wave's LDS reads first.  r04: without the lgkmcnt(0) hipcc is free to sink the tail of a step -- the last fragment reads'
+// `s_waitcnt lgkmcnt` and the MFMAs behind it -- BELOW the s_barrier (it did, in conv_halo_f16_ct_kernel: two ds_read_b128 of
+// the weight stage in flight across the barrier).  The next step's global_load_lds then restages that buffer one barrier after
+// reads that have not returned: a write-after-read race that never showed on a quiet chip (an LDS read returns long before a copy
+// lands) and corrupted ~0.2 % of the launches once another stream kept the CUs' LDS queues busy (tools/diag_kernels_under_load.py:
+// whole weight-fragment rows stale for one wave).  The rule (cdna_hip_programming.md, LDS-DMA staging): restage a buffer one
+// phase after its last read only when an lgkmcnt before the barrier retired those reads.
 __device__ __forceinline__ void pp_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }

@@ -163,6 +163,53 @@ def complete_flow(flow_model: FlowCompleter, flows: torch.Tensor, flow_masks_u8:
     return out
 
 
+def flows_overlapped(models: Models, frames: torch.Tensor, flow_masks_u8: torch.Tensor, config: ProPainterConfig):
+    """compute_flow + complete_flow for a clip of SEVERAL sub-videos (T - 1 > subvideo_length) with RAFT of sub-video k + 1
+    running under the flow completion of sub-video k (r04; propainter_inference.py:314-341 runs the stages one
+    after the other, :115-144 the sub-videos one after the other).  RAFT is per-pair independent (tests/test_raft.py), so it is
+    issued range by range on the launch stream -- exactly the pairs the next sub-video's completion reads, 5-flow halo included
+    -- and each completion goes to a side stream behind an event: the recurrence's ~1 600 small, latency-bound launches per
+    sub-video fill the gaps of RAFT's large kernels instead of having the chip to themselves.  Same sub-video plan, same
+    kernels, same arithmetic as compute_flow() + complete_flow(): bit-identical (the long-clip fixtures run through here).
+    -> (raw flows, completed flows), each fp32 [2,T-1,H,W,2]."""
+    T, H, W, _ = frames.shape
+    n, sv, pad = T - 1, config.subvideo_length, 5
+    dev = frames.device
+    gt = torch.empty(2, n, H, W, 2, device=dev)
+    pred = torch.empty_like(gt)
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    gt.record_stream(side)
+    pred.record_stream(side)
+    done = 0
+    for f in range(0, n, sv):
+        s, e = max(0, f - pad), min(n, f + sv + pad)
+        if e > done:          # the pairs this sub-video still misses
+            ff, fb = models.raft_model(frames[done:e + 1], config.raft_iter)
+            gt[0, done:e] = ff
+            gt[1, done:e] = fb
+            done = e
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            sub = models.flow_model(gt[:, s:e].contiguous(), flow_masks_u8[s:e + 1].contiguous())
+            own = min(n, f + sv) - f
+            pred[:, f:f + own] = sub[:, f - s:f - s + own]
+    main.wait_stream(side)
+    return gt, pred
+
+
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = str(dev)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+    return _SIDE_STREAMS[key]
+
+
 def image_propagation(frames: torch.Tensor, masks_u8: torch.Tensor, flows: torch.Tensor, config: ProPainterConfig):
     """-> (prop_frames fp32 [T,H,W,3], updated_masks u8 [T,H,W]); the blend with the input frames is fused
     into the encoder-input packing kernel by the caller."""
@@ -238,10 +285,15 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     md = torch.as_tensor(masks_dilated_u8).to(dev).contiguous()
     T, H, W, _ = fr_u8.shape
     frames = frames_f32 if frames_f32 is not None else ops.frames_from_u8(fr_u8)  # to_tensors(): x/255*2-1 (image_utils.py:191)
-    gt = compute_flow(models.raft_model, frames, config)
-    mark("raft")
-    pred = complete_flow(models.flow_model, gt, fm, config.subvideo_length)
-    mark("flow_completion")
+    if (T - 1 > config.subvideo_length and fr_u8.is_cuda and os.environ.get("PP_SUBVIDEO_OVERLAP", "1") != "0"
+            and not torch.cuda.is_current_stream_capturing()):
+        gt, pred = flows_overlapped(models, frames, fm, config)     # several sub-videos: RAFT of k+1 under completion of k
+        mark("raft+flow_completion(overlapped)")
+    else:
+        gt = compute_flow(models.raft_model, frames, config)
+        mark("raft")
+        pred = complete_flow(models.flow_model, gt, fm, config.subvideo_length)
+        mark("flow_completion")
     prop, upd = image_propagation(frames, md, pred, config)
     mark("image_propagation")
     gen = models.inpaint_model

@@ -274,6 +274,43 @@ def test_linear_of_unfold_equals_unfold_then_linear(backend, pp_knobs):
         assert (got.cpu().double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.gpu
+def test_f16_kernels_are_bit_stable_next_to_a_busy_stream(hip_lib, pp_knobs):
+    """r04 regression: conv_halo_f16_ct_kernel restaged a weight buffer one barrier after LDS reads hipcc had let slip below that
+    barrier (pp_device.h: pp_barrier now retires the wave's LDS reads first).  Alone on the chip the race never showed; with
+    another stream keeping the LDS queues busy ~0.2 % of the launches computed with stale weight rows (found when r04 put RAFT
+    of the next sub-video under the flow completion of the current one).  Here the 3x3 convolutions of the flow-completion step run
+    on a side stream next to a large PP_F32X2 convolution: every launch must reproduce the quiet result bit for bit."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1)
+    B, h, w = 2, 45, 80
+    x = torch.randn(B, h, w, 128, device=dev, generator=g).half()
+    big = torch.randn(64, 90, 160, 128, device=dev)
+    lspec = ops.make_conv_spec(torch.randn(128, 128, 3, 3) * 0.05, torch.zeros(128), torch.float32, padding=1, split=True).to(dev)
+    lout = torch.empty(64, 90, 160, 128, device=dev)
+    side = torch.cuda.Stream(dev)
+    pp_knobs(PP_CONV_KSPLIT="0", PP_CONV_HALO="force")           # the halo-tile kernels also for the 128 -> 128 layer
+    for cout, odt in ((432, torch.float32), (128, torch.float16)):
+        spec = ops.make_conv_spec(torch.randn(cout, 128, 3, 3) * 0.05, torch.randn(cout), torch.float16, padding=1).to(dev)
+        ref = torch.empty(B, h, w, cout, device=dev, dtype=odt)
+        ops.conv2d(spec, [x], ref, act="leaky", act_param=0.1)
+        torch.cuda.synchronize()
+        bad = 0
+        for rep in range(300):
+            out = torch.full_like(ref, float("nan"))
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                for _ in range(5):
+                    ops.conv2d(spec, [x], out, act="leaky", act_param=0.1)
+            ops.conv2d(lspec, [big], lout)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            bad += 0 if torch.equal(out, ref) else 1
+        assert bad == 0, f"3x3 128->{cout}: {bad} of 300 runs next to a busy stream differ from the quiet run"
+
+
 @pytest.mark.parametrize("halo", ["0", "force"])
 def test_epilogue_from_a_channel(backend, halo, pp_knobs):
     """`epi_from` (ABI v6): RAFT's GRU computes the z and r gates (update.py:41-43) in ONE 256-channel PP_F32X2 convolution

@@ -126,3 +126,36 @@ def test_undamped_recurrences_saturate(hip_lib, monkeypatch):
     assert bool(torch.isfinite(tr["updated_frames"]).all())
     assert big > 1e3, "the un-damped recurrence did not leave the usual range: the stress test is not stressing"
     assert out.dtype == torch.uint8 and out.float().std() > 1
+
+
+@pytest.mark.gpu
+def test_flow_completion_is_bit_stable_under_a_concurrent_stream(hip_lib):
+    """r04: the stage level of tests/test_conv.py::test_f16_kernels_are_bit_stable_next_to_a_busy_stream -- flow completion of one
+    sub-video on a side stream while RAFT runs on the launch stream (what pipeline.flows_overlapped does for clips of several
+    sub-videos) must give the bits of a quiet run; before the pp_barrier fix the ~1 600 launches of the recurrence differed in
+    every run (1.7-4.3 px inside the hole)."""
+    from comfyui_propainter_nodes_amd import image_utils, ops, pipeline, synth
+
+    T, H, W = 40, 184, 320
+    image, mask = synth.synthetic_clip(T, H, W)
+    frames_u8 = image_utils.image_to_uint8_frames(image)
+    frames_u8, fm, md = image_utils.prepare_frames_and_masks(frames_u8, mask, image_utils.ImageConfig(W, H, 5, 8, (W, H), T))
+    dev = torch.device("cuda:0")
+    models = pipeline.models_from_state_dicts(weights.synth_state_dicts(0), dev, "enable")
+    cfg = pipeline.ProPainterConfig(10, 10, 80, 6, "enable", T, dev, (W, H))
+    frames = ops.frames_from_u8(torch.from_numpy(frames_u8).to(dev))
+    fmd = torch.from_numpy(fm).to(dev)
+    gt = pipeline.compute_flow(models.raft_model, frames, cfg)
+    quiet = models.flow_model(gt, fmd).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev)
+    for rep in range(3):
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            out = models.flow_model(gt, fmd)
+        pipeline.compute_flow(models.raft_model, frames, cfg)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(out, quiet), f"run {rep} next to RAFT differs by {float((out - quiet).abs().max()):.3e} px"
