@@ -22,11 +22,14 @@ barrier + synchronize on both sides, MAX over ranks.
 
 Extra objects on the JSON line (N = 1): `roofline` for the dominant kernel (the MFMA implicit-GEMM conv) with
 `attention` (MFMA) and `corr_lookup` (HBM) entries beside it, all measured live with HIP events on the launch
-stream during one extra instrumented step; `parity` = the composed frames of the LAST TIMED STEP (the 80-frame
+stream during one extra instrumented step, and (r04) `e2e_frac`: every MFMA flop of the step priced at its family's nominal
+peak (PP_F32X2 at 2.5 PF / 3 products) against the wall time of the timed step -- the whole step as a fraction of the
+blended MFMA roofline; `parity` = the composed frames of the LAST TIMED STEP (the 80-frame
 clip itself) against tests/golden/cfg2_80f_node.npz, the output of the reference's own node on this clip (CPU fp32,
-minted once in the build container), plus the RAFT / completed flows of one traced pass; `cpu_baseline` (the
-oracle = CPU port of the reference timed on a bounded sample with a small thread sweep, and the reference's own
-timings recorded when the fixtures were minted); `node_call` (SURVEY.md 8d: the node method call-to-return);
+minted once in the build container), plus the RAFT / completed flows of one traced pass; `cpu_baseline` (`value` = the oracle = CPU port of the reference,
+timed HERE on a bounded sample with a small thread sweep; `reference_value` = the reference ITSELF on this 80-frame workload,
+its node method on CPU fp32, timed in the build container when the fixture was minted -- /root/reference does not exist on the
+GPU box); `node_call` (SURVEY.md 8d: the node method call-to-return);
 `f32_exact` (frames/s with PP_F32_GEMM=exact, i.e. RAFT on the f32 MFMA instructions instead of the f16x2 split).
 """
 from __future__ import annotations

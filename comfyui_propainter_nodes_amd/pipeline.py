@@ -285,8 +285,12 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     md = torch.as_tensor(masks_dilated_u8).to(dev).contiguous()
     T, H, W, _ = fr_u8.shape
     frames = frames_f32 if frames_f32 is not None else ops.frames_from_u8(fr_u8)  # to_tensors(): x/255*2-1 (image_utils.py:191)
-    if (T - 1 > config.subvideo_length and fr_u8.is_cuda and os.environ.get("PP_SUBVIDEO_OVERLAP", "1") != "0"
-            and not torch.cuda.is_current_stream_capturing()):
+    # (from three sub-videos on: with two, one completion of ~a tenth of RAFT's time is all there is to hide -- cfg 5 measured
+    #  2 170.8 vs 2 185.7 ms once and 2 521 ms on another box -- and the serial form keeps its lower variance)
+    n_sub = -(-(T - 1) // max(1, config.subvideo_length))
+    want_overlap = os.environ.get("PP_SUBVIDEO_OVERLAP", "auto")
+    if (fr_u8.is_cuda and not torch.cuda.is_current_stream_capturing()
+            and ((want_overlap == "auto" and n_sub >= 3) or (want_overlap == "1" and n_sub >= 2))):
         gt, pred = flows_overlapped(models, frames, fm, config)     # several sub-videos: RAFT of k+1 under completion of k
         mark("raft+flow_completion(overlapped)")
     else:

@@ -65,3 +65,30 @@ def test_pipeline_matches_reference_fixture(hip_lib, monkeypatch, case):
     assert frac_m < 5e-3 and frac_f < 5e-3
     assert frac_p < 5e-3 and psnr_p >= 40.0
     assert psnr_o >= 40.0 and frac_o < 1e-2
+
+
+@pytest.mark.gpu
+def test_subvideo_overlap_is_bit_identical_to_the_serial_stages(hip_lib, monkeypatch):
+    """r04 (pipeline.flows_overlapped): RAFT of sub-video k + 1 on the launch stream under the flow completion of sub-video k on a
+    side stream -- the default from three sub-videos on, forced here on the two-sub-video chunked fixture and on a four-sub-video
+    clip -- must give the serial pipeline's frames bit for bit (it did not until pp_barrier retired the LDS reads: pp_device.h)."""
+    from comfyui_propainter_nodes_amd import image_utils, synth
+
+    dev = torch.device("cuda:0")
+    g = np.load(GOLD / "e2e_chunked.npz")
+    T, H, W, iters, nl, rs, sv, _, _, seed = [int(v) for v in g["params"]]
+    models = pipeline.models_from_state_dicts(weights.synth_state_dicts(seed), dev)
+    cases = [(g["frames_u8"], g["flow_masks"], g["masks_dilated"], pipeline.ProPainterConfig(rs, nl, sv, iters, "enable", T, dev, (W, H)))]
+    T2, H2, W2 = 26, 128, 160                      # 25 flows in sub-videos of 7: four of them, the last one ragged
+    image, mask = synth.synthetic_clip(T2, H2, W2)
+    fr, fm, md = image_utils.prepare_frames_and_masks(image_utils.image_to_uint8_frames(image), mask,
+                                                      image_utils.ImageConfig(W2, H2, 3, 5, (W2, H2), T2))
+    cases.append((fr, fm, md, pipeline.ProPainterConfig(3, 4, 7, 3, "enable", T2, dev, (W2, H2))))
+    for fr, fm, md, cfg in cases:
+        monkeypatch.setenv("PP_SUBVIDEO_OVERLAP", "0")
+        serial = pipeline.run_inpainting(models, fr, fm, md, cfg)
+        monkeypatch.setenv("PP_SUBVIDEO_OVERLAP", "1")
+        for _ in range(2):
+            assert torch.equal(pipeline.run_inpainting(models, fr, fm, md, cfg), serial)
+        monkeypatch.delenv("PP_SUBVIDEO_OVERLAP")
+        assert torch.equal(pipeline.run_inpainting(models, fr, fm, md, cfg), serial)      # the default rule
