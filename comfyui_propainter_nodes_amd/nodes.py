@@ -324,11 +324,12 @@ def _run_sharded(devices: list, config: ProPainterConfig, load_slab, fm, md, tm:
     virtual = len({str(d) for d in devices}) < len(devices)
     backends = []
     for d in devices:
-        if virtual:     # ranks sharing a device must not share a model object (its captured hipGraphs own static buffers)
-            sds, prov = W.get_state_dicts(0)
-            m = models_from_state_dicts(sds, d, config.fp16, prov)
-        else:
-            m = initialize_models(d, config.fp16)
+        with torch.cuda.device(d):      # weight repacking launches kernels: the HIP current device must be the model's
+            if virtual:     # ranks sharing a device must not share a model object (its captured hipGraphs own static buffers)
+                sds, prov = W.get_state_dicts(0)
+                m = models_from_state_dicts(sds, d, config.fp16, prov)
+            else:
+                m = initialize_models(d, config.fp16)
         backends.append(D.GpuBackend(m, config))
     comp = D.run_multi_device(backends, config, load_slab, fm, md, devices, gather_root=0)
     tm.mark(f"pipeline({len(devices)} ranks)")

@@ -134,6 +134,12 @@ def check_device(*tensors: torch.Tensor) -> None:
             raise RuntimeError(
                 "libpropainter_mi355 needs tensors on the MI355X (got a CPU tensor); there is no CPU fallback"
             )
+        elif t.device.index != torch.cuda.current_device():
+            # hipLaunchKernel resolves the kernel for the CURRENT device: launching onto a stream of another device is undefined.
+            # A process that drives several GPUs makes the tensor's device current first (distributed.run_multi_device: one thread
+            # per device; `with torch.cuda.device(d)` elsewhere).
+            raise RuntimeError(f"tensor on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: "
+                               "make the tensor's device current before calling libpropainter_mi355")
 
 
 def nhwc_view(t: torch.Tensor) -> tuple[int, int, int, int, int]:

@@ -295,7 +295,10 @@ def _multi_device_case(devices):
     single = pipeline.run_inpainting(pipeline.models_from_state_dicts(sds, dev0), fr_h.to(dev0), fm, md, cfg)
     # one model object per rank (ranks that share a device must not share captured graphs), graphs ON: the runner gives every
     # rank its own compute stream and captures with thread-local error mode
-    backends = [D.GpuBackend(pipeline.models_from_state_dicts(sds, d), cfg) for d in devices]
+    backends = []
+    for d in devices:
+        with torch.cuda.device(d):
+            backends.append(D.GpuBackend(pipeline.models_from_state_dicts(sds, d), cfg))
     got = D.run_multi_device(backends, cfg, lambda r, lo, hi, d: fr_h[lo:hi].to(d), fm, md, devices, gather_root=0)
     assert got.device == dev0
     return got.cpu(), single
