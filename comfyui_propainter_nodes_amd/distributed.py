@@ -437,13 +437,16 @@ def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8,
             req.wait()
         return {peer: buf.to(dev) for peer, buf in bufs.items()}
 
+    # PP_P2P_ASYNC=0: complete every posted exchange at once (the blocking form of r02) -- a switch for operators should the
+    # overlap of batch_isend_irecv with the compute stream misbehave on some RCCL build; the default keeps exchanges in flight
+    blocking = os.environ.get("PP_P2P_ASYNC", "1") == "0"
     try:
         t = next(gen)
         while True:
             if isinstance(t, tuple) and t[0] == "p2p_start":
-                out = post(t[1], t[2])
+                out = ("done", finish(post(t[1], t[2]))) if blocking else post(t[1], t[2])
             elif isinstance(t, tuple) and t[0] == "p2p_wait":
-                out = finish(t[1])
+                out = t[1][1] if (isinstance(t[1], tuple) and len(t[1]) == 2 and t[1][0] == "done") else finish(t[1])
             elif isinstance(t, tuple):
                 out = finish(post(t[1], t[2]))
             else:
