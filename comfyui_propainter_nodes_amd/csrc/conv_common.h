@@ -433,6 +433,7 @@ int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // ... and its halo-tile form for stride-1 multi-tap convolutions (conv_halo.hip); returns 1 when not eligible
 int launch_halo_split(void* stream, const ConvK& k, int Z);
 int launch_halo_f16(void* stream, const ConvK& k, int Z, bool out_f16);
+int launch_halo_f16_small_cout(void* stream, const ConvK& k, int Z, bool out_f16);   // <= 16 output channels, 3x3 (PP_CONV_SMALL_HALO)
 // conv_gemm_f16.hip: 1x1 / stride-1 / unpadded single-segment f16 layers (plain GEMMs); returns 1 when not eligible
 int launch_gemm_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 // ... its patch-gather form (pp_conv2d_params.flat_taps); PP_ERR_UNSUPPORTED when the layer is not eligible

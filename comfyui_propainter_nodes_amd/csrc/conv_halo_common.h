@@ -24,11 +24,11 @@ constexpr int kHaloMaxRows = 192;
 static inline int halo_mode() { return options().halo; }
 
 // Geometry + eligibility shared by both forms; returns false when the flat-tile kernels should run instead.
-static inline bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* g, int TH = 8) {
+static inline bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* g, int TH = 8, int min_cout = 33) {
   const int mode = halo_mode();
   if (mode == 0) return false;
   const int ntaps = k.kh * k.kw;
-  if (ntaps < 2 || k.sh != 1 || k.sw != 1 || k.pad_mode != PP_PAD_ZEROS || k.Cout <= 32) return false;
+  if (ntaps < 2 || k.sh != 1 || k.sw != 1 || k.pad_mode != PP_PAD_ZEROS || k.Cout < min_cout) return false;
   g->hw = kHaloTW + (k.kw - 1) * k.dw;
   g->hrows = (TH + (k.kh - 1) * k.dh) * g->hw;
   if (g->hrows > max_rows) return false;
@@ -38,7 +38,7 @@ static inline bool halo_geometry(const ConvK& k, int Z, int max_rows, HaloGeom* 
   g->tiles_x = (k.Wo + kHaloTW - 1) / kHaloTW;
   g->tiles_y = (k.Ho + TH - 1) / TH;
   const int64_t ntiles = (int64_t)k.N * g->tiles_x * g->tiles_y;
-  const int64_t blocks = ntiles * ((k.Cout + 127) / 128) * Z;
+  const int64_t blocks = ntiles * ((k.Cout + 127) / 128) * Z;   // (a lower bound of the work-groups for narrower tiles)
   if (blocks >= ((int64_t)1 << 30)) return false;
   if (mode != 2) {
     if (blocks < 224) return false;  // small problems: the 32-pixel flat tiles fill the chip better

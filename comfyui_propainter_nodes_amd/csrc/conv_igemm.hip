@@ -93,6 +93,10 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   if (bad != PP_OK) return bad;
   const int Z = (int)p->Z;
   if (k.flat_taps && p->dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: flat_taps needs PP_F16");
+  if (k.Cout <= 4 && !k.flat_taps && p->dtype == PP_F16) {
+    const int rs = launch_halo_f16_small_cout(stream, k, Z, p->out_dtype == PP_F16);
+    if (rs != 1) return rs;
+  }
   if (k.Cout <= 4 && !k.flat_taps) {  // 2-3 output channels on a 32-channel MFMA tile are wasted matrix work: streaming vector-ALU kernel
     const int rd = launch_direct_small_cout(stream, k, Z, p->dtype, p->out_dtype == PP_F16);
     if (rd != 1) return rd;

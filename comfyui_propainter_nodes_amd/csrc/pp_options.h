@@ -12,6 +12,8 @@
 //   PP_CONV_DIRECT   0 | force   <= 4-output-channel streaming kernel off / regardless of the image size
 //   PP_CONV_ORDER    launch      flat-tile kernels: work-groups in launch order (pixel tiles first) instead of XCD-contiguous,
 //                                channel-tile-adjacent order (conv_common.h: flat_tile_of)
+//   PP_CONV_SMALL_HALO 0         <= 4-output-channel 3x3 f16 layers on the vector-ALU kernel of conv_direct.hip instead of 16-channel halo
+//                                MFMA tiles (r04 default: the generator's 64 -> 3 output layer 300 -> 186 us per launch)
 //   PP_CONV_GEMM     0 | force   the GEMM kernel for 1x1 f16 layers (conv_gemm_f16.hip) off / for every eligible layer whatever its size
 //   PP_CONV_GEMM_CFG 1..5        pin one tile configuration of that kernel (tuning; conv_gemm_f16.hip: launch_gemm_t)
 //   PP_CONV_TRACE    (set)       print which convolution kernel family ran (debugging aid)
@@ -28,6 +30,7 @@ struct Options {
   int direct;   // 0 off, 1 auto, 2 force
   int trace;
   int conv_order;  // 1 (default): XCD-contiguous, channel tiles adjacent; 0: launch order
+  int small_halo;  // 1: 3x3 f16 layers with <= 4 output channels on 16-channel halo MFMA tiles instead of the vector-ALU kernel
   int gemm;        // 0 off, 1 auto, 2 force
   int gemm_cfg;    // 0 auto, 1..5 pinned
   int deform_xcd;  // 1 (default): the deformable-sampling kernels walk their pixel blocks in XCD-contiguous order
