@@ -360,7 +360,8 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, aux
                 and spec.kw <= 3 and spec.pad_mode == "zeros" and n * ho * wo >= 16384 and os.environ.get("PP_CONV_DIRECT") != "0"
                 and (x0.dtype == torch.float16 or out.dtype == torch.float32)):
             # (r04: 3x3 f16 layers of this kind run on 16-channel halo MFMA tiles unless PP_CONV_SMALL_HALO=0 -- conv_halo_f16.hip)
-            on_mfma = (x0.dtype == torch.float16 and spec.kh == 3 and spec.kw == 3 and os.environ.get("PP_CONV_SMALL_HALO") != "0"
+            on_mfma = (x0.dtype == torch.float16 and spec.kh == 3 and spec.kw == 3 and sum(spec.seg_channels) > 32
+                       and os.environ.get("PP_CONV_SMALL_HALO") != "0"
                        and os.environ.get("PP_CONV_HALO") != "0" and n * (-(-ho // 8)) * (-(-wo // 16)) >= 224)
             if not on_mfma:
                 key = "direct"
