@@ -311,6 +311,27 @@ def test_f16_kernels_are_bit_stable_next_to_a_busy_stream(hip_lib, pp_knobs):
         assert bad == 0, f"3x3 128->{cout}: {bad} of 300 runs next to a busy stream differ from the quiet run"
 
 
+def test_small_cout_on_mfma_tiles(backend, pp_knobs):
+    """r04: 3x3 f16 layers with at most 4 output channels and at least two channel chunks (the generator's 64 -> 3 output layer) run on
+    16-channel tiles of the compile-time-tap halo kernel (conv_halo_f16.hip: launch_halo_f16_small_cout) instead of the vector-ALU
+    kernel: against torch, f16 and fp32 output, into a wider output view (the node's [.., 4] buffer: the padding channel must stay
+    untouched), partial tiles both ways; PP_CONV_SMALL_HALO=0 and single-chunk layers keep the vector-ALU kernel."""
+    g = torch.Generator().manual_seed(61)
+    for small_halo in ("1", "0"):
+        pp_knobs(PP_CONV_SMALL_HALO=small_halo, PP_CONV_HALO="force", PP_CONV_DIRECT="force")
+        for N, H, W, C, Cout, odt in ((2, 19, 37, 64, 3, torch.float16), (1, 9, 33, 40, 2, torch.float32), (1, 16, 16, 32, 4, torch.float16)):
+            x = torch.randn(N, H, W, C, generator=g).half()
+            w = torch.randn(Cout, C, 3, 3, generator=g) * 0.05
+            b = torch.randn(Cout, generator=g)
+            spec = ops.make_conv_spec(w, b, torch.float16, padding=1).to(backend)
+            out = torch.full((N, H, W, 4), float("nan"), dtype=odt, device=backend)
+            ops.conv2d(spec, [x.to(backend)], out[..., :Cout], act="tanh")
+            ref = torch.tanh(F.conv2d(x.float().permute(0, 3, 1, 2).double(), w.half().double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+            got = out.cpu()
+            assert (got[..., :Cout].double() - ref).abs().max().item() < (2e-3 if odt == torch.float16 else 1e-5)
+            assert Cout == 4 or bool(torch.isnan(got[..., Cout:]).all())
+
+
 @pytest.mark.parametrize("halo", ["0", "force"])
 def test_epilogue_from_a_channel(backend, halo, pp_knobs):
     """`epi_from` (ABI v6): RAFT's GRU computes the z and r gates (update.py:41-43) in ONE 256-channel PP_F32X2 convolution
