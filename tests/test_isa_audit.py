@@ -32,3 +32,21 @@ def test_hidden_loads_are_never_touched_in_flight(source, nkernels):
     assert "s_swappc" not in text  # no real calls: helper lambdas are always inlined
     scratch = re.findall(r"\.private_segment_fixed_size: (\d+)", text)
     assert scratch and all(int(v) == 0 for v in scratch), scratch
+
+
+def test_every_barrier_of_an_lds_dma_kernel_retires_its_lds_reads_first():
+    """The r04 race (csrc/pp_device.h: pp_barrier): in a kernel that restages LDS buffers by global_load_lds, an
+    `s_waitcnt lgkmcnt(0)` must stand between a wave's last ds_reads and the barrier that lets the other waves overwrite
+    the buffer -- hipcc sinks that wait below the barrier when left to itself.  Audits the disassembly of the code objects
+    INSIDE the shipped library (tools/shipped_isa.py; no recompilation; the pre-fix objects fail it: 52 of 56 barriers of
+    conv_halo_f16.hip)."""
+    import shipped_isa as S
+
+    from comfyui_propainter_nodes_amd import build
+
+    if not S.tools_available():
+        pytest.skip("no llvm-objcopy / llvm-objdump")
+    build.build_hip()
+    r = S.audit_barriers()
+    assert r["dma_kernels"] >= 80 and r["barriers"] >= 250, r   # every LDS-DMA kernel family is inside the library
+    assert not r["violations"], r["violations"][:10]
