@@ -2,6 +2,7 @@
 sequence of clang offload bundles, one per translation unit; each holds one hipv4-amdgcn-amd-amdhsa--gfx950 entry.
 
     python tools/shipped_isa.py [--barriers]        # kernel count per code object / the barrier audit below
+    python tools/shipped_isa.py --resources         # registers, LDS, scratch and spills of every kernel (markdown table)
 
 audit_barriers(): the r04 race.  A kernel that restages an LDS buffer by LDS-DMA (global_load_lds) right after a barrier must
 have retired its own ds_reads of that buffer BEFORE the barrier: hipcc is free to sink the `s_waitcnt lgkmcnt(0)` of the last
@@ -107,7 +108,48 @@ def audit_barriers(lib: Path = LIB) -> dict:
     return res
 
 
+def kernel_resources(lib: Path = LIB) -> list[dict]:
+    """One record per kernel from the code objects' metadata notes (what the loader uses to size a wave)."""
+    rows = []
+    keys = {"name": ".name", "vgpr": ".vgpr_count", "agpr": ".agpr_count", "sgpr": ".sgpr_count",
+            "lds_static": ".group_segment_fixed_size", "scratch": ".private_segment_fixed_size",
+            "vgpr_spills": ".vgpr_spill_count", "sgpr_spills": ".sgpr_spill_count", "max_wg": ".max_flat_workgroup_size"}
+    for image in code_objects(lib):
+        with tempfile.TemporaryDirectory() as td:
+            obj = Path(td) / "co.o"
+            obj.write_bytes(image)
+            notes = subprocess.run([_tool("llvm-readelf"), "--notes", str(obj)], check=True, capture_output=True, text=True).stdout
+        for blk in re.split(r"\n  - (?=\.agpr_count:)", notes)[1:]:
+            rec = {}
+            for k, field in keys.items():
+                m = re.search(r"(?:^|\n)\s*" + re.escape(field) + r":\s+(\S+)", blk)
+                v = m.group(1) if m else "0"
+                rec[k] = v if k == "name" else int(v)
+            rows.append(rec)
+    return rows
+
+
+def _demangle(names: list[str]) -> list[str]:
+    tool = _tool("llvm-cxxfilt") or shutil.which("c++filt")
+    if tool is None:
+        return names
+    out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
+    return [re.sub(r"^void ", "", x) for x in out[:len(names)]]
+
+
 def main(argv: list[str]) -> int:
+    if "--resources" in argv:
+        rows = sorted(kernel_resources(), key=lambda r: (-(r["vgpr"] + r["agpr"]), r["name"]))
+        names = _demangle([r["name"] for r in rows])
+        print("| kernel | VGPR | AGPR | waves / SIMD | SGPR | static LDS | scratch B | VGPR spills | SGPR spills |")
+        print("|---|---|---|---|---|---|---|---|---|")
+        for r, n in zip(rows, names):
+            regs = max(r["vgpr"] + r["agpr"], 1)
+            alloc = (regs + 7) // 8 * 8
+            waves = min(8, 512 // alloc)
+            print(f"| `{n[:110]}` | {r['vgpr']} | {r['agpr']} | {waves} | {r['sgpr']} | {r['lds_static']} | {r['scratch']} | "
+                  f"{r['vgpr_spills']} | {r['sgpr_spills']} |")
+        return 0
     if "--barriers" in argv:
         r = audit_barriers()
         print(f"{r['dma_kernels']} kernels with LDS-DMA, {r['barriers']} barriers, {len(r['violations'])} without a retired-reads wait")
