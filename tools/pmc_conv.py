@@ -11,7 +11,9 @@ from comfyui_propainter_nodes_amd import lib, ops  # noqa: E402
 CASES = [
     # name, split, dtype, N, H, W, segC, Cout, k, pad
     ("gru_split", True, torch.float32, 158, 45, 80, [128, 128], 256, (1, 5), (0, 2)),
-    ("gru_exact", False, torch.float32, 158, 45, 80, [128, 128], 256, (1, 5), (0, 2)),
+    ("gru_5x1_split", True, torch.float32, 158, 45, 80, [128, 128], 256, (5, 1), (2, 0)),
+    ("convc2_split", True, torch.float32, 158, 45, 80, [256], 192, (3, 3), (1, 1)),
+    ("fh1_split", True, torch.float32, 158, 45, 80, [128], 256, (3, 3), (1, 1)),
     ("enc_f16", False, torch.float16, 16, 90, 160, [256], 384, (3, 3), (1, 1)),
 ]
 
