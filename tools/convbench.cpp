@@ -150,7 +150,18 @@ static void run(const Shape& s, int iters) {
   int cin = 0;
   for (int c : s.segC) cin += c;
   const double flops = 2.0 * s.N * p.Ho * p.Wo * s.Cout * cin * s.kh * s.kw;
-  printf("{\"name\": \"%s\", \"ms\": %.4f, \"TFLOPs\": %.1f}\n", s.name, ms, flops / ms / 1e9);
+  // PP_CONVBENCH_SUM=1: a checksum of the output bits (A/B of kernel variants that must agree bit for bit)
+  unsigned long long sum = 0;
+  if (getenv("PP_CONVBENCH_SUM")) {
+    std::vector<unsigned char> host(on * esz);
+    CK(hipMemcpy(host.data(), out, on * esz, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i + 8 <= host.size(); i += 8) {
+      unsigned long long v;
+      memcpy(&v, &host[i], 8);
+      sum = sum * 1099511628211ull + v;
+    }
+  }
+  printf("{\"name\": \"%s\", \"ms\": %.4f, \"TFLOPs\": %.1f, \"out_hash\": \"%016llx\"}\n", s.name, ms, flops / ms / 1e9, sum);
   fflush(stdout);
   for (void* b : bufs) CK(hipFree(b));
 }
