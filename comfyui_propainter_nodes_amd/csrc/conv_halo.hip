@@ -39,8 +39,19 @@ namespace pp {
 //    read into a scalar register once, so the LDS-DMA destinations (M0) are scalar arithmetic;
 //  * the pipeline decisions (which tap fetches the next pixel tile, which one stores it, the counted waits) are resolved at
 //    compile time.
+//
+// Experiment hook for the next occupancy A/B (r04 counters: matrix pipe 53-61 % busy, 2 waves per SIMD, the cover comes from
+// INDEPENDENT work-groups): -DPP_HALO_TRIM64 (tools/build_variant.sh) sends every layer to the 64-channel x (8 x 16) tile (152
+// registers) and trims the pixel tile to its HROWS rows, so that THREE work-groups fit a CU (3 x <= 53.4 KB) instead of two.  Not
+// defined in the product build: the constant folds away (the product's code objects are unchanged, tools/shipped_isa.py).
+#ifdef PP_HALO_TRIM64
+constexpr bool kHaloTrim64 = true;
+#else
+constexpr bool kHaloTrim64 = false;
+#endif
+
 template <int WC, int WP, int TC, int TP, int KH, int KW>
-__global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_ct_kernel(const ConvK p, const HaloGeom g) {
+__global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)) conv_halo_split_ct_kernel(const ConvK p, const HaloGeom g) {
   typedef float OT;
   constexpr int NT = WC * WP * 64;
   constexpr int TH = WP * TP;
@@ -53,7 +64,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_ct_kernel(con
   constexpr int HROWS = (TH + KH - 1) * HW;
   constexpr int XPASS = (HROWS + XROWS - 1) / XROWS;
   constexpr int WPASS = BCP / WROWS;
-  constexpr int XBYTES = XPASS * XROWS * XP, WSTAGE = BCP * ROWB;
+  constexpr int XBYTES = (kHaloTrim64 ? HROWS : XPASS * XROWS) * XP, WSTAGE = BCP * ROWB;
   constexpr int NX = 2 * XPASS;
   constexpr int NTAPS = KH * KW;
   constexpr float LINV = 1.f / 2048.f;
@@ -165,7 +176,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_ct_kernel(con
   auto store_x = [&]() PP_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
-      if (XPASS * XROWS > HROWS + XROWS - 1 && xrow0 + i * XROWS >= XPASS * XROWS) continue;
+      if (kHaloTrim64 && xrow0 + i * XROWS >= HROWS) continue;   // trimmed tile: the rows past the halo tile do not exist
       f4 v[2] = {xreg[i][0], xreg[i][1]};
       if (!((xok >> (2 * i)) & 1)) v[0] = f4{0.f, 0.f, 0.f, 0.f};
       if (!((xok >> (2 * i)) & 2)) v[1] = f4{0.f, 0.f, 0.f, 0.f};
@@ -315,7 +326,7 @@ static int launch_halo_ct_cfg(void* stream, const ConvK& k, int Z, HaloGeom g) {
   constexpr int BCP = (BC + NT / 8 - 1) / (NT / 8) * (NT / 8);
   constexpr int HROWS = (8 + KH - 1) * (kHaloTW + KW - 1);
   constexpr int XPASS = (HROWS + NT / 4 - 1) / (NT / 4);
-  const size_t smem = (size_t)XPASS * (NT / 4) * 160 + (size_t)3 * BCP * 128;
+  const size_t smem = (size_t)(kHaloTrim64 ? HROWS : XPASS * (NT / 4)) * 160 + (size_t)3 * BCP * 128;
   g.nct = (k.Cout + BC - 1) / BC;
   dim3 grid((unsigned)(g.ntiles * g.nct), 1u, (unsigned)Z);
   PP_ALLOW_BIG_LDS((&conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), smem);
@@ -333,7 +344,7 @@ int launch_halo_split(void* stream, const ConvK& k, int Z) {
   // (A two-group form -- one 8-wave work-group per CU, two pixel tiles sharing the weight ring, group 1 held half a step
   // behind group 0 by an extra barrier so that one group's MFMA burst always met the other's loads -- was built, checked
   // on the MI355X and measured SLOWER: RAFT GRU 1x5 228 vs 277 TF/s, 3x3 256->192 254 vs 320; removed)
-  if (k.Cout > 64) {
+  if (k.Cout > 64 && !kHaloTrim64) {
     const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
     const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
     if (waste96 + 32 <= waste128) return launch_halo_any<2, 2, 3, 4>(stream, k, Z, g);  //  96 x (8 x 16)

@@ -170,7 +170,12 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
       fprintf(stderr, "pp_emu: mmap failed\n");
       abort();
     }
-    w.smem = (unsigned char*)aligned_alloc(64, 160 * 1024);
+    // dynamic LDS: the kernel may touch smem_bytes only; everything behind it is a canary checked after the last block (a
+    // work-group writing past its launch's allocation would corrupt its neighbour's LDS on the GPU)
+    constexpr size_t kLdsBytes = 160 * 1024, kCanaryTail = 4096;
+    w.smem = (unsigned char*)aligned_alloc(64, kLdsBytes + kCanaryTail);
+    const size_t used = std::min(smem_bytes, kLdsBytes);
+    memset(w.smem + used, 0xA5, kLdsBytes + kCanaryTail - used);
     w.bs.scratch = (unsigned char*)aligned_alloc(64, (kMaxThreads / kWave) * kWave * 64);
     w.body = &body;
     tw = &w;
@@ -185,6 +190,11 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
     }
     tw = nullptr;
     dyn_smem = nullptr;
+    for (size_t i = used; i < kLdsBytes + kCanaryTail; ++i)
+      if (w.smem[i] != 0xA5) {
+        fprintf(stderr, "pp_emu: a kernel wrote dynamic LDS byte %zu, past the %zu bytes of its launch\n", i, smem_bytes);
+        abort();
+      }
     munmap(w.stacks, stack_total);
     free(w.smem);
     free(w.bs.scratch);
@@ -198,7 +208,6 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
     for (int i = 0; i < nworkers; ++i) ts.emplace_back(work);
     for (auto& t : ts) t.join();
   }
-  (void)smem_bytes;
 }
 
 }  // namespace pp_emu
