@@ -435,7 +435,7 @@ static int launch_halo_f16_t(void* stream, const ConvK& k, int Z) {
   if (!halo_geometry(k, Z, 320, &g)) return 1;
   const bool big = g.hrows > 192;  // dilated 3x3 (12 x 20, 14 x 22): five 64-row copy passes instead of three
   if (options().halo_ct && k.kh == 3 && k.kw == 3 && k.dh == 1 && k.dw == 1) {
-    if (k.Cout > 64) {
+    if (k.Cout > 64 && !options().halo_c64) {
       const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
       const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
       if (waste96 + 32 <= waste128) return launch_halo_f16_ct_cfg<OT, 2, 2, 3, 4>(stream, k, Z, g);

@@ -92,6 +92,8 @@ static void load_options() {
     else if (e[0] == 'c') o.tile = 6;
     else o.tile = e[0] == 'l' ? 1 : (e[0] == 's' ? 2 : 0);
   }
+  o.halo_c64 = 0;
+  if (const char* e = getenv("PP_CONV_HALO_C64")) o.halo_c64 = e[0] == '1';
   o.small_halo = 1;
   if (const char* e = getenv("PP_CONV_SMALL_HALO")) o.small_halo = e[0] != '0';
   o.gemm = tri("PP_CONV_GEMM");

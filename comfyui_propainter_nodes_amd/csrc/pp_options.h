@@ -14,6 +14,9 @@
 //                                channel-tile-adjacent order (conv_common.h: flat_tile_of)
 //   PP_CONV_SMALL_HALO 0         <= 4-output-channel 3x3 f16 layers on the vector-ALU kernel of conv_direct.hip instead of 16-channel halo
 //                                MFMA tiles (r04 default: the generator's 64 -> 3 output layer 300 -> 186 us per launch)
+//   PP_CONV_HALO_C64 1           f16 compile-time-tap halo layers on 64-channel tiles whatever Cout: 48 KB and 100 registers per work-group,
+//                                THREE work-groups per CU instead of two (72 KB, 152-175 registers) -- the occupancy A/B the r04 SQ counters
+//                                ask for (profiles/r04_conv_counters.md); default 0 until measured
 //   PP_CONV_GEMM     0 | force   the GEMM kernel for 1x1 f16 layers (conv_gemm_f16.hip) off / for every eligible layer whatever its size
 //   PP_CONV_GEMM_CFG 1..5        pin one tile configuration of that kernel (tuning; conv_gemm_f16.hip: launch_gemm_t)
 //   PP_CONV_TRACE    (set)       print which convolution kernel family ran (debugging aid)
@@ -31,6 +34,7 @@ struct Options {
   int trace;
   int conv_order;  // 1 (default): XCD-contiguous, channel tiles adjacent; 0: launch order
   int small_halo;  // 1: 3x3 f16 layers with <= 4 output channels on 16-channel halo MFMA tiles instead of the vector-ALU kernel
+  int halo_c64;    // 1: f16 compile-time-tap halo layers on 64-channel tiles whatever Cout (default 0)
   int gemm;        // 0 off, 1 auto, 2 force
   int gemm_cfg;    // 0 auto, 1..5 pinned
   int deform_xcd;  // 1 (default): the deformable-sampling kernels walk their pixel blocks in XCD-contiguous order

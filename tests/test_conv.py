@@ -245,6 +245,33 @@ def test_gemm_kernel_equals_flat_kernel(backend, cfg, pp_knobs):
         assert (outs[1].double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
 
 
+def test_halo_c64_knob_is_bit_identical(emu_lib, pp_knobs):
+    """r04: PP_CONV_HALO_C64=1 sends every 3x3 f16 compile-time-tap halo layer to the 64-channel tile (three work-groups per CU;
+    the occupancy A/B of profiles/r04_conv_counters.md, default off until timed).  A tile shape changes which work-group computes
+    an output, never the order of its K sum: bit-identical to the default selection for 96- and 128-channel-tile layers, partial
+    channel tiles, two input segments, f16 and fp32 outputs, a fused epilogue.  (Emulator only: the knob was added after the round's
+    last GPU call; tools/gpu_r5_first.sh times it and checks the whole step's parity with it on the MI355X.)"""
+    backend = torch.device("cpu")
+    g = torch.Generator().manual_seed(67)
+    for N, H, W, segC, Cout, odt, epi in ((1, 17, 35, [64], 128, torch.float16, None), (2, 9, 20, [32, 40], 192, torch.float16, "add"),
+                                          (1, 16, 16, [96], 200, torch.float32, None)):
+        x = [torch.randn(N, H, W, c, generator=g).half().to(backend) for c in segC]
+        w = torch.randn(Cout, sum(segC), 3, 3, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        aux = torch.randn(N, H, W, Cout, generator=g).to(odt).to(backend)
+        spec = ops.make_conv_spec(w, b, torch.float16, padding=1, seg_channels=segC).to(backend)
+        outs = []
+        for c64 in ("0", "1"):
+            pp_knobs(PP_CONV_HALO="force", PP_CONV_KSPLIT="0", PP_CONV_HALO_C64=c64)
+            out = torch.full((N, H, W, Cout), float("nan"), device=backend, dtype=odt)
+            ops.conv2d(spec, x, out, act="relu", **({"epi": "add", "aux1": aux} if epi else {}))
+            outs.append(out.cpu())
+        assert torch.equal(outs[0], outs[1]), (Cout, (outs[0].float() - outs[1].float()).abs().max())
+        xin = torch.cat([t.cpu() for t in x], -1).double().permute(0, 3, 1, 2)
+        ref = torch.relu(F.conv2d(xin, w.half().double(), b.double(), padding=1)).permute(0, 2, 3, 1) + (aux.cpu().double() if epi else 0)
+        assert (outs[1].double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_linear_of_unfold_equals_unfold_then_linear(backend, pp_knobs):
     """r04 (ABI v8, pp_conv2d_params.flat_taps): the Linear over F.unfold()'s tap-major patch vectors with the patches gathered
     inside the GEMM kernel must equal unfold (a copy) + the same Linear BIT FOR BIT -- the FusionFeedForward's fc2 on the folded
