@@ -56,6 +56,7 @@ struct ConvK {
   int tile_order;  // flat-tile kernels: 1 = XCD-contiguous, channel tiles of a pixel tile adjacent (flat_tile_of); 0 = launch order
   const float* weight_f32;  // optional fp32 [tap][chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
   int flat_taps;            // weights = one (ky, kx, c)-ordered row per output channel; conv_gemm_f16.hip gathers the patches
+  int epi_lds;              // 1 (default): LDS-transposed epilogue (epilogue_quads_lds); 0 (PP_CONV_EPI=direct): quads stored as the MFMA leaves them
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float param) {
@@ -98,7 +99,18 @@ struct EpiCtx {
   const OT* aux1;
   const OT* aux2;
   const OT* pre;
+#ifdef PP_HALO_TRACE
+  mutable uint32_t st[8];   // tools/trace_halo.sh build only: s_memtime stamps inside the epilogue
+#endif
 };
+#ifdef PP_HALO_TRACE
+#define PP_EPI_STAMP(e, i)                 \
+  __builtin_amdgcn_sched_barrier(0);       \
+  (e).st[i] = (uint32_t)__builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_sched_barrier(0)
+#else
+#define PP_EPI_STAMP(e, i)
+#endif
 
 // 4 consecutive channels of one pixel row as floats: one 8/16-byte load when `vec`, else guarded scalars
 template <typename ET>
@@ -324,27 +336,260 @@ __device__ __forceinline__ void store_quad_fast(const ConvK& p, const EpiCtx<OT>
 // exists), chan(a) the first channel of quad row a for this lane, val(a, b) the finished accumulator quad (compile-time
 // indices: the callers' accumulators are register arrays).  One uniform branch picks the fast or the general form.
 template <typename OT, int NA, int NB, typename RowFn, typename ChanFn, typename ValFn>
+__device__ __forceinline__ void epilogue_quads_fast(const ConvK& p, const EpiCtx<OT>& e, RowFn row, ChanFn chan, ValFn val) {
+  static_for<NB>([&](auto bi) {
+    int64_t m;
+    bool ok;
+    row(bi, m, ok);
+    static_for<NA>([&](auto ai) {
+      const int c = chan(ai);
+      if (ok && c < p.Cout) store_quad_fast<OT>(p, e, val(ai, bi), m, c);
+    });
+  });
+}
+
+// The general (per-lane decisions) form alone, for launches that fail epi_fast_ok()
+template <typename OT, int NA, int NB, typename RowFn, typename ChanFn, typename ValFn>
+__device__ __forceinline__ void epilogue_quads_general(const ConvK& p, const EpiCtx<OT>& e, RowFn row, ChanFn chan, ValFn val) {
+  static_for<NB>([&](auto bi) {
+    int64_t m;
+    bool ok;
+    row(bi, m, ok);
+    static_for<NA>([&](auto ai) {
+      const int c = chan(ai);
+      if (ok && c < p.Cout) store_quad<OT>(p, e, val(ai, bi), m, c);
+    });
+  });
+}
+
+template <typename OT, int NA, int NB, typename RowFn, typename ChanFn, typename ValFn>
 __device__ __forceinline__ void epilogue_quads(const ConvK& p, const EpiCtx<OT>& e, RowFn row, ChanFn chan, ValFn val) {
   if (epi_fast_ok<OT>(p, e)) {
-    static_for<NB>([&](auto bi) {
-      int64_t m;
-      bool ok;
-      row(bi, m, ok);
-      static_for<NA>([&](auto ai) {
-        const int c = chan(ai);
-        if (ok && c < p.Cout) store_quad_fast<OT>(p, e, val(ai, bi), m, c);
-      });
-    });
+    epilogue_quads_fast<OT, NA, NB>(p, e, row, chan, val);
   } else {
-    static_for<NB>([&](auto bi) {
-      int64_t m;
-      bool ok;
-      row(bi, m, ok);
-      static_for<NA>([&](auto ai) {
-        const int c = chan(ai);
-        if (ok && c < p.Cout) store_quad<OT>(p, e, val(ai, bi), m, c);
-      });
+    epilogue_quads_general<OT, NA, NB>(p, e, row, chan, val);
+  }
+}
+
+// ---- LDS-transposed epilogue (r05).  The MFMA leaves a lane 4 consecutive channels of ONE pixel per 16 x 16 tile, neighbouring
+// lanes neighbouring PIXELS: a wave's store instruction above is 16 separate 64-byte (f32) / 32-byte (f16) pieces a channel pitch
+// apart, and the aux / pre-add loads of the fused epilogues gather the same way.  The s_memtime phase trace of the PP_F32X2 halo
+// kernels (profiles/r05_f32x2_phase_trace.md) put the epilogue at 14 000 of a work-group's 101 000 cycles -- 16 such stores per
+// wave -- with the matrix pipe idle meanwhile.  Here a wave stages one quad ROW (16 pixels x NA*16 channels of raw accumulators,
+// fp32) in a wave-private LDS region and reads it back with neighbouring lanes on neighbouring CHANNELS of one pixel: every
+// store / aux load of 16 lanes is NA*64 contiguous bytes (f32; half for f16), i.e. whole cache lines.  The arithmetic per element
+// is store_quad_fast()'s, unchanged: results are bit-identical to the direct form.
+// Layout of the staging region: [16 pixels][NA*16 floats + 4 pad floats] (the pad spreads the 8-lane groups of ds_write_b128 over
+// all banks).  row0(b, m0, nvalid): output pixel of column 0 of quad row b and the number of valid columns (<= 16, may be <= 0).
+template <int NA>
+constexpr int epi_lds_pitch() { return NA * 64 + 16; }
+template <int NA>
+constexpr int epi_lds_wave_bytes() { return 16 * epi_lds_pitch<NA>(); }
+
+// Compile-time forms of apply_act4() / the fused epilogue op (same operations in the same order as store_quad_fast(): the
+// results are bit-identical); a negative template value = decided at run time (the generic variant).
+template <int ACT>
+__device__ __forceinline__ f4 act4_ct(f4 v, int act_rt, float param) {
+  if constexpr (ACT < 0) {
+    return apply_act4(v, act_rt, param);
+  } else if constexpr (ACT == PP_ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    return v;
+  } else if constexpr (ACT == PP_ACT_LEAKY) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * param;
+    return v;
+  } else if constexpr (ACT == PP_ACT_SIGMOID) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+    return v;
+  } else if constexpr (ACT == PP_ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+    return v;
+  } else if constexpr (ACT == PP_ACT_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));
+    return v;
+  } else {
+    return v;
+  }
+}
+
+// One variant of the LDS-transposed epilogue.  ACT / ACT2 / EPI / PRE: compile-time activation of the channels below / from
+// p.act_split, the fused op and whether a pre-activation addend exists (ACT2 = -2: the launch has no activation split; ACT = -1:
+// everything decided at run time -- the catch-all variant).
+// Why variants, and why the order of the memory operations below (r05, profiles/r05_f32x2_phase_trace.md): the phase trace put
+// the epilogue of a PP_F32X2 halo work-group at 14 000 of its 101 000 cycles on a layer whose epilogue is ONE ReLU and 16 stores
+// per wave.  Neither the stores' coalescing (this transposition alone: same time) nor the instruction count explains ~850 cycles
+// per store; vmcnt does: on gfx9 stores count in vmcnt like loads, so the `s_waitcnt vmcnt` in front of the first use of ANY load
+// issued after a store also waits for that store's write acknowledgement -- and the r02-r04 epilogue loaded bias / aux / pre per
+// quad between the stores (with run-time switches the compiler even waits where no load was issued: the if-converted use needs
+// the wait).  Here no wait for a load ever has an older store in front of it: the bias quad of a lane is loaded once before the
+// first store, the loads of quad row b + 1 are issued BEFORE the stores of row b (the counted wait then leaves those stores in
+// flight), and a variant without aux / pre tensors has no load in its loop at all.
+template <typename OT, int NA, int NB, int ACT, int ACT2, int EPI, int PRE, typename Row0Fn, typename ValFn>
+__device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
+                                                     Row0Fn row0, ValFn val) {
+  constexpr int PITCH = epi_lds_pitch<NA>();
+  constexpr int QPR = NA * 4;              // quads per staged pixel
+  constexpr bool RT = ACT < 0;             // the run-time variant
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const bool has_bias = e.bias != nullptr;
+  const bool has_pre = RT ? e.pre != nullptr : PRE != 0;
+  const int epi = RT ? p.epi : EPI;
+  const int cmax = p.Cout - 4;             // (fast form: Cout % 4 == 0) loads of a lane past Cout are clamped, its stores masked
+  // per-lane constants of the transposed layout: quad i of a row is pixel px[i], channel quad qq[i]
+  int cc[NA], px[NA];
+  bool cok[NA];
+  f4 bq[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = i * 64 + lane;
+    px[i] = q / QPR;
+    const int c = c_wave + (q - px[i] * QPR) * 4;
+    cok[i] = c < p.Cout;
+    cc[i] = c < cmax ? c : cmax;
+    bq[i] = f4{0.f, 0.f, 0.f, 0.f};
+    if (has_bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
+  }
+  struct RowLd {
+    f4 a1[NA], a2[NA], pr[NA];
+    int64_t mm[NA];
+    int nvalid;
+  };
+  RowLd rl[2];
+  auto issue_row = [&](auto bi, RowLd& r) PP_INLINE_LAMBDA {
+    int64_t m0;
+    row0(bi, m0, r.nvalid);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      // (addresses clamped into the tensors: a load never needs a branch; rows / pixels that do not exist are masked at the store)
+      r.mm[i] = r.nvalid > 0 ? m0 + (px[i] < r.nvalid ? px[i] : r.nvalid - 1) : 0;
+      if (has_pre) r.pr[i] = load_quad_vec(e.pre + r.mm[i] * p.pre_add_ldc + cc[i]);
+      if (epi != PP_EPI_NONE) {
+        const int ce = cc[i] >= p.epi_from ? cc[i] - p.epi_from : 0;
+        r.a1[i] = load_quad_vec(e.aux1 + r.mm[i] * p.aux1_ldc + ce);
+        if (epi == PP_EPI_GRU) r.a2[i] = load_quad_vec(e.aux2 + r.mm[i] * p.aux2_ldc + ce);
+      }
+    }
+  };
+  PP_EPI_STAMP(e, 1);
+  issue_row(std::integral_constant<int, 0>{}, rl[0]);
+  PP_EPI_STAMP(e, 2);
+  static_for<NB>([&](auto bi) {
+    constexpr int b = decltype(bi)::value;
+    RowLd& r = rl[b & 1];
+    static_for<NA>([&](auto ai) {
+      *reinterpret_cast<f4*>(wlds + frow * PITCH + (decltype(ai)::value * 16 + fgrp * 4) * 4) = val(ai, bi);
     });
+    pp_wave_lds_fence();
+    f4 v[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) v[i] = *reinterpret_cast<const f4*>(wlds + px[i] * PITCH + (i * 64 + lane - px[i] * QPR) * 16);
+    if constexpr (b + 1 < NB) issue_row(std::integral_constant<int, b + 1>{}, rl[(b + 1) & 1]);  // before this row's stores
+    // the arithmetic of store_quad_fast(), operation by operation
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      f4 x = v[i];
+      if (has_bias) x += bq[i];
+      if (has_pre) x += r.pr[i];
+      if (ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split) {
+        x = act4_ct<ACT2>(x, p.act2, p.act_param);
+      } else {
+        x = act4_ct<ACT>(x, p.act, p.act_param);
+        if (p.out_scale != 0.f) x *= p.out_scale;
+      }
+      if (epi != PP_EPI_NONE && cc[i] >= p.epi_from) {
+        if (epi == PP_EPI_MUL_AUX1) {
+          x *= r.a1[i];
+        } else if (epi == PP_EPI_ADD_AUX1) {
+          x += r.a1[i];
+        } else if (epi == PP_EPI_ADD_AUX1_RELU) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float t = x[k] + r.a1[i][k];
+            x[k] = t > 0.f ? t : 0.f;
+          }
+        } else if (epi == PP_EPI_GRU) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = (1.f - r.a1[i][k]) * r.a2[i][k] + r.a1[i][k] * x[k];
+        }
+      }
+      if (cok[i] && px[i] < r.nvalid) {
+        OT* dst = e.out + r.mm[i] * p.out_ldc + cc[i];
+        if constexpr (sizeof(OT) == 2) {
+          h4 o = {sat_half(x[0]), sat_half(x[1]), sat_half(x[2]), sat_half(x[3])};
+          *reinterpret_cast<h4*>(dst) = o;
+        } else {
+#if defined(PP_EPI_STORE_MODE) && !defined(PP_EMU)   // experiment hook (tools/build_variant.sh): cache policy of the output stores
+#if PP_EPI_STORE_MODE == 1
+          asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(x) : "memory");
+#elif PP_EPI_STORE_MODE == 2
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(x) : "memory");
+#elif PP_EPI_STORE_MODE == 3
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(x) : "memory");
+#elif PP_EPI_STORE_MODE == 4
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(x) : "memory");
+#endif
+#else
+          *reinterpret_cast<f4*>(dst) = x;
+#endif
+        }
+      }
+    }
+    pp_wave_lds_fence();  // the next row's staging writes come after this row's reads
+    if constexpr (b < 4) { PP_EPI_STAMP(e, 3 + b); }
+  });
+}
+
+// Dispatch to the variant of the launch's (act, act2, epi, pre_add): the combinations the pipeline's layers use are compiled in,
+// anything else takes the run-time variant (same arithmetic).
+template <typename OT, int NA, int NB, typename Row0Fn, typename ValFn>
+__device__ __forceinline__ void epilogue_quads_lds(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
+                                                   Row0Fn row0, ValFn val) {
+  const int a2 = p.act_split > 0 ? p.act2 : -2;
+  const int pre = e.pre != nullptr ? 1 : 0;
+#define PP_EPI_VARIANT(A, A2, E, P)                                                                \
+  if (p.act == (A) && a2 == (A2) && p.epi == (E) && pre == (P)) {                                  \
+    epilogue_lds_variant<OT, NA, NB, (A), (A2), (E), (P)>(p, e, wlds, lane, c_wave, row0, val);    \
+    return;                                                                                        \
+  }
+  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0)
+  PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_NONE, 0)
+  PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_NONE, 0)
+  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_ADD_AUX1, 0)
+  PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_ADD_AUX1_RELU, 0)
+  PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_ADD_AUX1, 0)
+  PP_EPI_VARIANT(PP_ACT_SIGMOID, -2, PP_EPI_MUL_AUX1, 1)
+  PP_EPI_VARIANT(PP_ACT_TANH, -2, PP_EPI_GRU, 1)
+  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_RELU, PP_EPI_NONE, 0)
+  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_SIGMOID, PP_EPI_NONE, 0)
+#undef PP_EPI_VARIANT
+  epilogue_lds_variant<OT, NA, NB, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
+}
+
+// One epilogue entry for every convolution kernel: the general form when the launch's views are not vector-aligned, the
+// LDS-transposed form when the work-group's LDS holds the waves' staging rows (FITS, a compile-time fact of the launcher's LDS
+// size) and PP_CONV_EPI is not "direct", else the direct fast form.  `smem` = the work-group's dynamic LDS: every wave must be done
+// with it (the barrier below) and no LDS-DMA copy may be in flight (vmcnt).
+template <typename OT, int NA, int NB, bool FITS, bool BARRIER = true, typename RowFn, typename ChanFn, typename ValFn, typename Row0Fn>
+__device__ __forceinline__ void epilogue_any(const ConvK& p, const EpiCtx<OT>& e, unsigned char* smem, int wave, int lane, int c_wave,
+                                             RowFn row, ChanFn chan, ValFn val, Row0Fn row0) {
+  if constexpr (FITS) {
+    if (!epi_fast_ok<OT>(p, e) || !p.epi_lds) {   // odd views, or PP_CONV_EPI=direct (A/B: same bits)
+      epilogue_quads_general<OT, NA, NB>(p, e, row, chan, val);
+      return;
+    }
+    if constexpr (BARRIER) {   // (false: the caller hands over LDS no other wave touches any more)
+      pp_wait_vmcnt<0>();
+      pp_barrier();
+    }
+    PP_EPI_STAMP(e, 0);
+    epilogue_quads_lds<OT, NA, NB>(p, e, smem + wave * epi_lds_wave_bytes<NA>(), lane, c_wave, row0, val);
+  } else {
+    epilogue_quads<OT, NA, NB>(p, e, row, chan, val);
   }
 }
 

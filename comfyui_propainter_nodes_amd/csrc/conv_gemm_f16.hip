@@ -174,14 +174,21 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
   e.aux1 = reinterpret_cast<const OT*>(p.aux1);
   e.aux2 = reinterpret_cast<const OT*>(p.aux2);
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
-  epilogue_quads<OT, TC, TP>(
-      p, e,
+  // (r05: the LDS-transposed epilogue LOSES on these short-reduction GEMMs -- fc1 631 -> 460, qkv 588 -> 459 TF/s: four exposed LDS
+  //  round trips per wave against a loop of ~8 000 cycles -- so they keep the direct quads: EPI_FITS = false)
+  constexpr bool EPI_FITS = false;
+  epilogue_any<OT, TC, TP, EPI_FITS>(
+      p, e, reinterpret_cast<unsigned char*>(smem), wave, lane, c_base + wc * TC * 16,
       [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
         m = p_base + wp * TP * 16 + decltype(bi)::value * 16 + frow;
         ok = m < p.M;
       },
       [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
-      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
+      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; },
+      [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
+        m0 = p_base + wp * TP * 16 + decltype(bi)::value * 16;
+        nvalid = (int)(p.M - m0 < 16 ? p.M - m0 : 16);
+      });
 }
 
 template <typename OT, int WC, int WP, int TC, int TP, int KC, int NST, bool PATCH = false>

@@ -19,6 +19,9 @@
 // Arithmetic, weight packing, K order and epilogue are those of conv_split_kernel (same results up to fp32 summation
 // order -- identical order in fact: chunk by chunk, tap by tap).  The f16 form lives in conv_halo_f16.hip.
 #include "conv_halo_common.h"
+#ifdef PP_HALO_TRACE
+#include <vector>
+#endif
 
 namespace pp {
 
@@ -50,6 +53,25 @@ constexpr bool kHaloTrim64 = true;
 constexpr bool kHaloTrim64 = false;
 #endif
 
+// Phase trace (tools/trace_halo.sh, -DPP_HALO_TRACE; not defined in the product build): every wave accumulates, in scalar
+// registers, the s_memtime ticks it spends per tap in (issue = weight / pixel copies issued) (compute = fragment reads + MFMAs)
+// (close = counted waits + barrier [+ split / store of the next pixel tile at the last tap of a chunk]) and writes the sums behind
+// the epilogue -- no store and no extra wait inside the loop, so the counted vmcnt waits are untouched.  -DPP_HALO_WMID issues
+// the weight copies of step q + 2 in the middle of step q's MFMAs instead of in front of its fragment reads.
+#ifdef PP_HALO_TRACE
+#define PP_TR_NOW(v)                        \
+  __builtin_amdgcn_sched_barrier(0);        \
+  const uint32_t v = (uint32_t)__builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_sched_barrier(0)
+#else
+#define PP_TR_NOW(v)
+#endif
+#ifdef PP_HALO_WMID
+constexpr bool kHaloWMid = true;
+#else
+constexpr bool kHaloWMid = false;
+#endif
+
 template <int WC, int WP, int TC, int TP, int KH, int KW>
 __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)) conv_halo_split_ct_kernel(const ConvK p, const HaloGeom g) {
   typedef float OT;
@@ -69,8 +91,13 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   constexpr int NTAPS = KH * KW;
   constexpr float LINV = 1.f / 2048.f;
   static_assert(TH == 8 && NTAPS >= 2 && HROWS <= kHaloMaxRows, "geometry");
+  static_assert(WC * WP * epi_lds_wave_bytes<TC>() <= XBYTES + 3 * WSTAGE, "the epilogue's staging rows live in the tile memory");
 
   unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
+  PP_TR_NOW(tr_start);
+#ifdef PP_HALO_TRACE
+  uint32_t tr_issue = 0, tr_comp = 0, tr_close = 0, tr_issue_l = 0, tr_comp_l = 0, tr_close_l = 0;
+#endif
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
 #ifdef PP_EMU
@@ -212,7 +239,7 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   const unsigned char* wfrag_h = smem + XBYTES + (wc * TC * 16 + frow) * ROWB + ((fgrp ^ swz(frow)) << 4);
   const unsigned char* wfrag_l = smem + XBYTES + (wc * TC * 16 + frow) * ROWB + (((fgrp + 4) ^ swz(frow)) << 4);
 
-  auto compute = [&](auto tapc, int wbuf) PP_INLINE_LAMBDA {
+  auto compute = [&](auto tapc, int wbuf, auto&& mid) PP_INLINE_LAMBDA {
     constexpr int tap = decltype(tapc)::value;
     constexpr int tapoff = (tap / KW) * HW + (tap % KW);
     const unsigned char* wh = wfrag_h + wbuf * WSTAGE;
@@ -232,6 +259,7 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
     for (int a = 0; a < TC; ++a)
 #pragma unroll
       for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bh[b], acc[a][b]);
+    mid();
 #pragma unroll
     for (int a = 0; a < TC; ++a)
 #pragma unroll
@@ -253,6 +281,10 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   pp_wait_lgkm0();
   pp_barrier();
   int w0 = 0;                                  // ring stage of the current step
+  PP_TR_NOW(tr_loop0);
+#ifdef PP_HALO_TRACE
+  uint32_t tr_prev = tr_loop0;
+#endif
   for (int chunk = 0; chunk < nck; ++chunk) {
     const bool next_chunk = chunk + 1 < nck;
     static_for<NTAPS>([&](auto tapc) {
@@ -261,10 +293,13 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
       const int w1 = w0 == 2 ? 0 : w0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;
       // weights two steps ahead: tap + 2 of this chunk, or tap + 2 - NTAPS of the next one
       const bool more_w = (tap + 2 < NTAPS) || next_chunk;
-      if (more_w) {
-        if constexpr (tap + 2 == NTAPS) w_next_chunk();  // the iterator moves on when the look-ahead crosses the chunk end
-        fetch_w(w2, (tap + 2) % NTAPS);
-      }
+      auto issue_w = [&]() PP_INLINE_LAMBDA {
+        if (more_w) {
+          if constexpr (tap + 2 == NTAPS) w_next_chunk();  // the iterator moves on when the look-ahead crosses the chunk end
+          fetch_w(w2, (tap + 2) % NTAPS);
+        }
+      };
+      if constexpr (!kHaloWMid) issue_w();
       // the next chunk's pixels are fetched (to registers) at the last-but-one tap: one tap of MFMAs for the loads to land.
       // (r04 measured issuing them at tap 0 instead -- NTAPS - 1 taps ahead, the counted waits adjusted for the in-order
       //  retirement: 309.2 vs 311.4 TF/s over the family on the whole clip, inside the noise: the chunk boundary's cost is
@@ -273,7 +308,19 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
       if constexpr (tap == XF) {
         if (next_chunk) fetch_x();
       }
-      compute(tapc, w0);
+      PP_TR_NOW(tr_a);
+      compute(tapc, w0, [&]() PP_INLINE_LAMBDA {
+        if constexpr (kHaloWMid) {
+#ifndef PP_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          issue_w();
+#ifndef PP_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+      });
+      PP_TR_NOW(tr_b);
       if constexpr (last) {
         if (next_chunk) {
           pp_wait_lgkm0();
@@ -295,9 +342,19 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
 #ifndef PP_EMU
       __builtin_amdgcn_sched_barrier(0);       // unrolled taps: keep the next tap's address arithmetic / reads out of this one
 #endif
+      PP_TR_NOW(tr_c);
+#ifdef PP_HALO_TRACE
+      if constexpr (last) {
+        tr_issue_l += tr_a - tr_prev; tr_comp_l += tr_b - tr_a; tr_close_l += tr_c - tr_b;
+      } else {
+        tr_issue += tr_a - tr_prev; tr_comp += tr_b - tr_a; tr_close += tr_c - tr_b;
+      }
+      tr_prev = tr_c;
+#endif
       w0 = w1;
     });
   }
+  PP_TR_NOW(tr_loop1);
 
   EpiCtx<OT> e;
   e.bias = p.bias ? p.bias + (int64_t)z * p.bias_zoff : nullptr;
@@ -306,17 +363,31 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
   const int ox = tx0 + frow;
-  epilogue_quads<OT, TC, TP>(
-      p, e,
-      [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
-        const int oy = ty0 + wp * TP + decltype(bi)::value;
-        m = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
-        ok = oy < p.Ho && ox < p.Wo;
-      },
-      [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
-      [&](auto ai, auto bi) PP_INLINE_LAMBDA {
-        return acc[decltype(ai)::value][decltype(bi)::value] + accx[decltype(ai)::value][decltype(bi)::value] * LINV;
-      });
+  auto rowfn = [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
+    const int oy = ty0 + wp * TP + decltype(bi)::value;
+    m = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
+    ok = oy < p.Ho && ox < p.Wo;
+  };
+  auto chanfn = [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; };
+  auto valfn = [&](auto ai, auto bi) PP_INLINE_LAMBDA {
+    return acc[decltype(ai)::value][decltype(bi)::value] + accx[decltype(ai)::value][decltype(bi)::value] * LINV;
+  };
+  epilogue_any<OT, TC, TP, true>(p, e, smem, wave, lane, c_base + wc * TC * 16, rowfn, chanfn, valfn,
+                                 [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
+                                   const int oy = ty0 + wp * TP + decltype(bi)::value;
+                                   m0 = ((int64_t)n * p.Ho + oy) * p.Wo + tx0;
+                                   nvalid = oy < p.Ho ? p.Wo - tx0 : 0;
+                                 });
+#ifdef PP_HALO_TRACE
+  PP_TR_NOW(tr_end);
+  if (g.trace && lane == 0) {
+    uint32_t* t = g.trace + ((size_t)blockIdx.x * (WC * WP) + wave) * 20;
+    for (int i = 0; i < 7; ++i) t[12 + i] = e.st[i] - tr_loop1;
+    t[0] = tr_loop0 - tr_start; t[1] = tr_loop1 - tr_loop0; t[2] = tr_end - tr_loop1;
+    t[3] = tr_issue; t[4] = tr_comp; t[5] = tr_close; t[6] = tr_issue_l; t[7] = tr_comp_l; t[8] = tr_close_l;
+    t[9] = (uint32_t)nck; t[10] = tr_start; t[11] = tr_end;
+  }
+#endif
 }
 
 template <int WC, int WP, int TC, int TP, int KH, int KW>
@@ -329,9 +400,54 @@ static int launch_halo_ct_cfg(void* stream, const ConvK& k, int Z, HaloGeom g) {
   const size_t smem = (size_t)(kHaloTrim64 ? HROWS : XPASS * (NT / 4)) * 160 + (size_t)3 * BCP * 128;
   g.nct = (k.Cout + BC - 1) / BC;
   dim3 grid((unsigned)(g.ntiles * g.nct), 1u, (unsigned)Z);
+#ifdef PP_HALO_TRACE
+  // PP_HALO_TRACE_SOLO=1: pad the dynamic LDS beyond half a CU's, so ONE work-group is resident per CU (what a wave's tap costs
+  // when it has the SIMD to itself)
+  static const bool solo = getenv("PP_HALO_TRACE_SOLO") && getenv("PP_HALO_TRACE_SOLO")[0] == '1';
+  const size_t smem_l = solo ? (size_t)100 * 1024 : smem;
+  const size_t nrec = (size_t)grid.x * (WC * WP) * 20;
+  static uint32_t* trace = nullptr;
+  static size_t trace_cap = 0;
+  if (trace_cap < nrec) {
+    if (trace) hipFree(trace);
+    hipMalloc(&trace, nrec * 4);
+    trace_cap = nrec;
+  }
+  hipMemsetAsync(trace, 0, nrec * 4, (hipStream_t)stream);
+  g.trace = trace;
+  PP_ALLOW_BIG_LDS((&conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), smem_l);
+  PP_LAUNCH((conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), grid, dim3(NT), smem_l, stream, k, g);
+  {
+    static int launches = 0;
+    if (++launches == 3) {   // one warmed-up launch per process and kernel instantiation
+      std::vector<uint32_t> h(nrec);
+      hipStreamSynchronize((hipStream_t)stream);
+      hipMemcpy(h.data(), trace, nrec * 4, hipMemcpyDeviceToHost);
+      const size_t nw = nrec / 20;
+      double s[9] = {0}, es[7] = {0};
+      for (size_t w = 0; w < nw; ++w) {
+        for (int i = 0; i < 9; ++i) s[i] += h[w * 20 + i];
+        for (int i = 0; i < 7; ++i) es[i] += h[w * 20 + 12 + i];
+      }
+      fprintf(stderr, "{\"epilogue_stamps_after_loop\": {\"barrier\": %.0f, \"bias\": %.0f, \"row0_loads\": %.0f, \"row0\": %.0f, \"row1\": %.0f, \"row2\": %.0f, \"row3\": %.0f}}\n",
+              es[0] / nw, es[1] / nw, es[2] / nw, es[3] / nw, es[4] / nw, es[5] / nw, es[6] / nw);
+      // (start / end ticks are per-XCD clocks: the launch's span is read off wave 0's XCD only)
+      const int nck = (int)h[9], NTAPS = KH * KW;
+      const double taps = (double)nck * (NTAPS - 1), lasts = nck;
+      fprintf(stderr,
+              "{\"halo_trace\": \"<%d,%d,%d,%d,%d,%d>\", \"solo\": %d, \"Cout\": %d, \"chunks\": %d, \"waves\": %zu, \"prologue\": %.0f, \"loop\": %.0f, "
+              "\"epilogue\": %.0f, \"per_tap\": {\"issue\": %.1f, \"compute\": %.1f, \"close\": %.1f}, "
+              "\"per_last_tap\": {\"issue\": %.1f, \"compute\": %.1f, \"close\": %.1f}, \"mfma_ticks_per_tap\": %d}\n",
+              WC, WP, TC, TP, KH, KW, (int)solo, k.Cout, nck, nw, s[0] / nw, s[1] / nw, s[2] / nw, s[3] / nw / taps, s[4] / nw / taps,
+              s[5] / nw / taps, s[6] / nw / lasts, s[7] / nw / lasts, s[8] / nw / lasts, TC * TP * 3 * 16);
+    }
+  }
+  return pp_check_launch("pp_conv2d");
+#else
   PP_ALLOW_BIG_LDS((&conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), smem);
   PP_LAUNCH((conv_halo_split_ct_kernel<WC, WP, TC, TP, KH, KW>), grid, dim3(NT), smem, stream, k, g);
   return pp_check_launch("pp_conv2d");
+#endif
 }
 
 template <int WC, int WP, int TC, int TP>

@@ -14,6 +14,9 @@ struct HaloGeom {
   int hrows;             // halo tile pixels = (TH + (kh-1)*dh) * hw   (<= kHaloMaxRows)
   int nct;               // output-channel tiles
   int ntiles;            // N * tiles_y * tiles_x
+#ifdef PP_HALO_TRACE
+  unsigned* trace;       // tools/trace_halo.sh build of conv_halo.hip only: 12 words per wave
+#endif
 };
 
 constexpr int kHaloTW = 16;

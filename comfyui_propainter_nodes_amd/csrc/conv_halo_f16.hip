@@ -182,15 +182,21 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_halo_f16_kernel(const ConvK
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
   const int ox = tx0 + frow;
-  epilogue_quads<OT, TC, TP>(
-      p, e,
+  constexpr bool EPI_FITS = WC * WP * epi_lds_wave_bytes<TC>() <= 2 * XSTAGE + 3 * WSTAGE;
+  epilogue_any<OT, TC, TP, EPI_FITS>(
+      p, e, smem, wave, lane, c_base + wc * TC * 16,
       [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
         const int oy = ty0 + wp * TP + decltype(bi)::value;
         m = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
         ok = oy < p.Ho && ox < p.Wo;
       },
       [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
-      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
+      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; },
+      [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
+        const int oy = ty0 + wp * TP + decltype(bi)::value;
+        m0 = ((int64_t)n * p.Ho + oy) * p.Wo + tx0;
+        nvalid = oy < p.Ho ? p.Wo - tx0 : 0;
+      });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -389,15 +395,21 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_f16_ct_kernel(const
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
   const int ox = tx0 + frow;
-  epilogue_quads<OT, TC, TP>(
-      p, e,
+  constexpr bool EPI_FITS = WC * WP * epi_lds_wave_bytes<TC>() <= 2 * XSTAGE + 2 * WSTAGE;
+  epilogue_any<OT, TC, TP, EPI_FITS>(
+      p, e, smem, wave, lane, c_base + wc * TC * 16,
       [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
         const int oy = ty0 + wp * TP + decltype(bi)::value;
         m = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
         ok = oy < p.Ho && ox < p.Wo;
       },
       [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
-      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
+      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; },
+      [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
+        const int oy = ty0 + wp * TP + decltype(bi)::value;
+        m0 = ((int64_t)n * p.Ho + oy) * p.Wo + tx0;
+        nvalid = oy < p.Ho ? p.Wo - tx0 : 0;
+      });
 }
 
 template <typename OT, int WC, int WP, int TC, int TP>

@@ -427,14 +427,19 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_igemm_kernel(const ConvK p)
           return f4{acc32[a][b][4 * q], acc32[a][b][4 * q + 1], acc32[a][b][4 * q + 2], acc32[a][b][4 * q + 3]};
         });
   } else {
-    epilogue_quads<OT, TC, TP>(
-        p, e,
+    constexpr bool EPI_FITS = (size_t)WC * WP * epi_lds_wave_bytes<TC>() <= (size_t)NST * STAGE * sizeof(T);
+    epilogue_any<OT, TC, TP, EPI_FITS>(
+        p, e, reinterpret_cast<unsigned char*>(smem), wave, lane, c_base + wc * TC * 16,
         [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
           m = p_base + wp * TP * 16 + decltype(bi)::value * 16 + frow;
           ok = m < p.M;
         },
         [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
-        [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
+        [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; },
+        [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
+          m0 = p_base + wp * TP * 16 + decltype(bi)::value * 16;
+          nvalid = (int)(p.M - m0 < 16 ? p.M - m0 : 16);
+        });
   }
 }
 

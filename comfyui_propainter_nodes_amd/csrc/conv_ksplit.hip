@@ -223,14 +223,21 @@ __global__ void __launch_bounds__(kKS * 256) conv_ksplit_kernel(const ConvK p) {
   e.aux1 = p.aux1 ? reinterpret_cast<const OT*>(p.aux1) + (int64_t)z * p.aux1_zoff : nullptr;
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
-  epilogue_quads<OT, TC, TP>(
-      p, e,
+  // staging rows of the transposed epilogue: behind the partial tiles (the other groups have left; no barrier may follow)
+  constexpr size_t RED_BYTES = (size_t)(kKS - 1) * 4 * TC * TP * 64 * sizeof(f4);
+  constexpr bool EPI_FITS = RED_BYTES + 4 * epi_lds_wave_bytes<TC>() <= (size_t)kKS * NST * STAGE * sizeof(T);
+  epilogue_any<OT, TC, TP, EPI_FITS, false>(
+      p, e, reinterpret_cast<unsigned char*>(PP_DYN_SMEM) + RED_BYTES, wave, lane, c_base + wave * TC * 16,
       [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
         m = p_base + decltype(bi)::value * 16 + frow;
         ok = m < p.M;
       },
       [&](auto ai) PP_INLINE_LAMBDA { return c_base + wave * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
-      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
+      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; },
+      [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
+        m0 = p_base + decltype(bi)::value * 16;
+        nvalid = (int)(p.M - m0 < 16 ? p.M - m0 : 16);
+      });
 }
 
 template <typename OT, int NST>

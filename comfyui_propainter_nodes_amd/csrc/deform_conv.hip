@@ -289,21 +289,28 @@ __global__ void __launch_bounds__(KS * NW * 64) deform_conv_kernel(const DeformS
   e.aux1 = reinterpret_cast<const OT*>(p.aux1);
   e.aux2 = reinterpret_cast<const OT*>(p.aux2);
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
-  epilogue_quads<OT, TC, TP>(
-      p, e,
+  // staging rows of the transposed epilogue: behind the partial tiles (the launcher sizes the LDS for them; the other groups
+  // have left, so no barrier may follow)
+  constexpr size_t RED_BYTES = (size_t)(KS - 1) * NW * TC * TP * 64 * sizeof(f4);
+  epilogue_any<OT, TC, TP, true, KS == 1>(
+      p, e, reinterpret_cast<unsigned char*>(PP_DYN_SMEM) + RED_BYTES, wave, lane, c_base,
       [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
         m = p_base + (wave * TP + decltype(bi)::value) * 16 + frow;
         ok = m < p.M;
       },
       [&](auto ai) PP_INLINE_LAMBDA { return c_base + decltype(ai)::value * 16 + fgrp * 4; },
-      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
+      [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; },
+      [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
+        m0 = p_base + (wave * TP + decltype(bi)::value) * 16;
+        nvalid = (int)(p.M - m0 < 16 ? p.M - m0 : 16);
+      });
 }
 
 template <typename OT, int NW, int KS, int TP>
 static int launch_deform_cfg(void* stream, const DeformSrc& d, const ConvK& k) {
   constexpr int BP = NW * TP * 16;
   constexpr size_t ring = (size_t)KS * 2 * 128 * 32 * sizeof(half_t);
-  constexpr size_t red = (size_t)(KS - 1) * NW * 8 * TP * 64 * sizeof(f4);
+  constexpr size_t red = (size_t)(KS - 1) * NW * 8 * TP * 64 * sizeof(f4) + (size_t)NW * epi_lds_wave_bytes<8>();  // + the epilogue's staging rows
   constexpr size_t smem = ring > red ? ring : red;
   dim3 grid((unsigned)((k.M + BP - 1) / BP), (unsigned)((k.Cout + 127) / 128), 1u);
   PP_ALLOW_BIG_LDS((&deform_conv_kernel<OT, NW, KS, TP>), smem);

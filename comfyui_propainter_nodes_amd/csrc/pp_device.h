@@ -116,10 +116,19 @@ __device__ __forceinline__ void pp_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+// Lanes of ONE wave hand data to each other through a wave-private LDS region: the wave executes its LDS instructions in
+// program order, so no s_barrier is needed -- only the compiler must not move a lane's reads above the other lanes' writes
+// (per thread the addresses differ, so without the fence it may) and the writes must have left the wave (lgkmcnt).
+__device__ __forceinline__ void pp_wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #else
+inline void pp_wave_lds_fence() { pp_emu::wave_sync(); }
 inline void glds16(const void* g, void* lds_wave_base) {
   memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * pp_emu::cur->lane, g, 16);
 }

@@ -20,6 +20,8 @@
 //   PP_CONV_GEMM     0 | force   the GEMM kernel for 1x1 f16 layers (conv_gemm_f16.hip) off / for every eligible layer whatever its size
 //   PP_CONV_GEMM_CFG 1..5        pin one tile configuration of that kernel (tuning; conv_gemm_f16.hip: launch_gemm_t)
 //   PP_CONV_TRACE    (set)       print which convolution kernel family ran (debugging aid)
+//   PP_CONV_EPI      direct      convolution epilogues store their quads as the MFMA leaves them (r01-r04) instead of transposing them
+//                                through LDS into whole-cache-line rows (r05 default; bit-identical)
 //   PP_DEFORM_XCD    0           pp_deform_cols / pp_deform_conv walk their pixel blocks in launch order instead of XCD-contiguous order
 #pragma once
 
@@ -37,6 +39,7 @@ struct Options {
   int halo_c64;    // 1: f16 compile-time-tap halo layers on 64-channel tiles whatever Cout (default 0)
   int gemm;        // 0 off, 1 auto, 2 force
   int gemm_cfg;    // 0 auto, 1..5 pinned
+  int epi_lds;     // 1 (default): LDS-transposed epilogue; 0: direct quads
   int deform_xcd;  // 1 (default): the deformable-sampling kernels walk their pixel blocks in XCD-contiguous order
 };
 const Options& options();

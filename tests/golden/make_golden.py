@@ -265,12 +265,16 @@ def _rel(a, b):
 
 def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_length, ref_stride, subvideo_length,
                   mask_dilates=5, flow_mask_dilates=8, width_scale=1.2, height_scale=1.0, seed=0, flow_stride=4,
-                  save=True, check_oracle=True, mask_kind="static", weights_variant=""):
+                  save=True, check_oracle=True, mask_kind="static", weights_variant="", keep_every=1, keep_seams=0):
     """BASELINE-config fixtures minted THROUGH THE REFERENCE'S NODE METHODS (propainter_nodes.py:93-154 / :231-310),
     fp16 "disable" on CPU, with the stage tensors captured on the way.  Stored compactly (the inputs are regenerable
     from the seed): RAFT flows as f32 on a 2*`flow_stride` sub-grid, completed flows as f16 on a `flow_stride` sub-grid, updated masks bit-packed, the node's IMAGE output only
     where masks_dilated == 1 (elsewhere it must equal the prepared input frames bit for bit, which the test checks
-    against its own host plumbing), the two mask outputs bit-packed."""
+    against its own host plumbing), the two mask outputs bit-packed.
+    r05, long clips (`keep_every` > 1): the masked pixels of the IMAGE output and the completed flows are stored for every
+    `keep_every`-th frame and for the `keep_seams` frames either side of each sub-video boundary only (`out_keep` / `flow_keep` =
+    the kept indices); every other frame is represented by the sum of its masked pixels (`out_frame_sums`) -- the fixture of a
+    640-frame clip stays at the size of a 170-frame one."""
     import time
 
     sds = weights.synth_state_dicts(seed, weights_variant)
@@ -335,16 +339,38 @@ def run_node_case(name, kind, T, H, W, *, width, height, raft_iter, neighbor_len
             "updated_masks": f"{_rel(tr['updated_masks'], cap['um']):.2e}",
             "composed_maxdiff_u8": int(np.abs(ocomp.astype(np.int32) - out_u8.astype(np.int32)).max()),
             "composed_frac_diff": float((ocomp != out_u8).mean())})
+    if save and keep_every > 1:
+        # keep the raw run first: a slip in the compaction below must not cost hours of reference time
+        np.savez(Path(tempfile.gettempdir()) / f"raw_{name}.npz", out_u8=out_u8, md=md, fm=fm,
+                 um=cap["um"][0, :, 0].numpy().astype(np.uint8),
+                 gt=np.stack([cap["gt"][i][0].numpy() for i in (0, 1)], 0)[:, :, :, ::2 * flow_stride, ::2 * flow_stride],
+                 pred=np.stack([cap["pred"][i][0].numpy() for i in (0, 1)], 0)[:, :, :, ::flow_stride, ::flow_stride])
     if save:
         s = flow_stride
         sel = md.astype(bool)
+        if keep_every > 1:
+            keep = set(range(0, T, keep_every)) | {T - 1}
+            for b in range(subvideo_length, T, subvideo_length):
+                keep |= {f for f in range(b - keep_seams, b + keep_seams) if 0 <= f < T}
+            keep = np.array(sorted(keep))
+            fkeep = keep[keep < T - 1]
+            extra.update(out_keep=keep, flow_keep=fkeep,
+                         out_frame_sums=np.array([int(out_u8[t][sel[t]].astype(np.uint64).sum()) for t in range(T)]))
+            sel = sel.copy()
+            drop = np.ones(T, bool)
+            drop[keep] = False
+            sel[drop] = False
+            psel = fkeep
+        else:
+            psel = np.arange(T - 1)
         np.savez_compressed(
             HERE / f"{name}.npz",
             kind=np.array(kind), params_json=np.array(__import__("json").dumps(dict(
                 T=T, H=H, W=W, width=width, height=height, width_scale=width_scale, height_scale=height_scale, seed=seed,
-                flow_stride=s, mask_kind=mask_kind, weights_variant=weights_variant, **common))),
+                flow_stride=s, mask_kind=mask_kind, weights_variant=weights_variant, keep_every=keep_every,
+                keep_seams=keep_seams, **common))),
             gt_flow=np.stack([cap["gt"][i][0, :, :, ::2 * s, ::2 * s].numpy() for i in (0, 1)], 0).astype(np.float32),
-            pred_flow=np.stack([cap["pred"][i][0, :, :, ::s, ::s].numpy() for i in (0, 1)], 0).astype(np.float16),
+            pred_flow=np.stack([cap["pred"][i][0, psel][:, :, ::s, ::s].numpy() for i in (0, 1)], 0).astype(np.float16),
             updated_masks=np.packbits(cap["um"][0, :, 0].numpy().astype(np.uint8)),
             out_masked=out_u8[sel],                                    # [n_masked_pixels, 3] in (t, y, x) order
             out_crc=np.array([int(out_u8.astype(np.uint64).sum())]),
@@ -394,6 +420,19 @@ NODE_CASES = {
                                       ref_stride=10, subvideo_length=80, flow_stride=8, weights_variant="contractive"),
     "cfg4_170f_node": dict(kind="inpaint", T=170, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
                            ref_stride=10, subvideo_length=80, flow_stride=8),
+    # --- r05: the BASELINE configurations at their stated LENGTH (VERDICT r04 missing #3) -----------------------------------------
+    # configs[3] IN FULL: 640 frames of 640x360 = 8 sub-videos of 80 (the plan the 8-GPU SCALE run shards); stored for every 8th
+    # frame + the 3 frames either side of each of the 7 sub-video boundaries, per-frame sums for the rest
+    "cfg4_640f_node": dict(kind="inpaint", T=640, H=360, W=640, width=640, height=360, raft_iter=20, neighbor_length=10,
+                           ref_stride=10, subvideo_length=80, flow_stride=8, keep_every=8, keep_seams=3),
+    # configs[4] IN FULL: 160 frames of 1280x720, neighbor_length 20, ref_stride 10, two sub-videos
+    "cfg5_160f_node": dict(kind="inpaint", T=160, H=720, W=1280, width=1280, height=720, raft_iter=20, neighbor_length=20,
+                           ref_stride=10, subvideo_length=80, flow_stride=16, keep_every=4, keep_seams=3),
+    # configs[4]'s size and mode with the CONTRACTIVE weight variant: completed flows asserted pointwise INSIDE the hole at
+    # 1280x720, nl 20, two sub-videos
+    "cfg5_90f_contractive_node": dict(kind="inpaint", T=90, H=720, W=1280, width=1280, height=720, raft_iter=20, neighbor_length=20,
+                                      ref_stride=10, subvideo_length=80, flow_stride=16, weights_variant="contractive",
+                                      keep_every=2, keep_seams=3),
 }
 
 
@@ -448,7 +487,8 @@ def main():
         if args.case in ("all", name):
             run_case(name, save=not args.no_save, **kw)
     for name, kw in NODE_CASES.items():
-        if args.case in ("all", name) or (args.case == "edge" and name in EDGE_CASES):
+        long_case = kw.get("keep_every", 1) > 1           # hours of reference time each: only when named
+        if (args.case == "all" and not long_case) or args.case == name or (args.case == "edge" and name in EDGE_CASES):
             run_node_case(name, save=not args.no_save, check_oracle=not args.no_oracle, **kw)
 
 
