@@ -56,6 +56,7 @@ struct ConvK {
   int tile_order;  // flat-tile kernels: 1 = XCD-contiguous, channel tiles of a pixel tile adjacent (flat_tile_of); 0 = launch order
   const float* weight_f32;  // optional fp32 [tap][chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
   int flat_taps;            // weights = one (ky, kx, c)-ordered row per output channel; conv_gemm_f16.hip gathers the patches
+  float acc_scale;          // PP_F32X2: 1 / (power-of-two scale of the packed weights); 1 otherwise
   int epi_lds;              // 1 (default): LDS-transposed epilogue (epilogue_quads_lds); 0 (PP_CONV_EPI=direct): quads stored as the MFMA leaves them
 };
 
@@ -593,33 +594,7 @@ __device__ __forceinline__ void epilogue_any(const ConvK& p, const EpiCtx<OT>& e
   }
 }
 
-// PP_F32X2 low term of v given its high term h = f16_rtz(v): (v - h) * 2048, saturated to the f16 range.  The
-// remainder only reaches the limit for |v| >= 32752 (ulp(h) = 32: a remainder of 31.99 scales to 65515, which would
-// round to infinity): there the representation degrades gracefully (absolute error <= 0.016 up to |v| = 65504, and
-// v saturates at +-65536 beyond) instead of poisoning the accumulators with Inf - Inf.
-__device__ __forceinline__ float split_lo(float v, float h) {
-  const float r = (v - h) * 2048.f;
-  return fminf(fmaxf(r, -65504.f), 65504.f);
-}
-// The split of two values as the kernels' pixel staging does it, 4 vector-ALU operations per value: h = f16_rtz(v)
-// (packed convert), t = v - h (exact; one fma with the f16 operand converted in the instruction), t clamped to +-32
-// (only bites for |v| >= 65536, where it makes the representation saturate), l = f16_rtz(2048 t) (packed convert:
-// round-toward-zero never overflows to infinity, so the scaled remainder needs no second clamp; split_lo() above
-// with a round-to-nearest convert took 7).  l's rounding differs from the host-side weight split by at most one f16
-// ulp of a term that is itself 2^-11 of v.
-__device__ __forceinline__ void split_pair(float c0, float c1, h2& hh, h2& ll) {
-  hh = cvt_pkrtz_f16(c0, c1);
-  float t0 = __builtin_fmaf((float)hh[0], -1.f, c0), t1 = __builtin_fmaf((float)hh[1], -1.f, c1);
-#ifdef PP_EMU
-  t0 = fminf(fmaxf(t0, -32.f), 32.f);
-  t1 = fminf(fmaxf(t1, -32.f), 32.f);
-#else
-  t0 = __builtin_amdgcn_fmed3f(t0, -32.f, 32.f);
-  t1 = __builtin_amdgcn_fmed3f(t1, -32.f, 32.f);
-#endif
-  ll = cvt_pkrtz_f16(t0 * 2048.f, t1 * 2048.f);
-}
-
+// (the PP_F32X2 operand split lives in pp_device.h: split_pair)
 // one 16-byte f16 MFMA fragment from LDS
 __device__ __forceinline__ h8 lds_frag(const void* ptr) { return *reinterpret_cast<const h8*>(ptr); }
 

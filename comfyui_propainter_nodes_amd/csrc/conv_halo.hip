@@ -89,7 +89,6 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   constexpr int XBYTES = (kHaloTrim64 ? HROWS : XPASS * XROWS) * XP, WSTAGE = BCP * ROWB;
   constexpr int NX = 2 * XPASS;
   constexpr int NTAPS = KH * KW;
-  constexpr float LINV = 1.f / 2048.f;
   static_assert(TH == 8 && NTAPS >= 2 && HROWS <= kHaloMaxRows, "geometry");
   static_assert(WC * WP * epi_lds_wave_bytes<TC>() <= XBYTES + 3 * WSTAGE, "the epilogue's staging rows live in the tile memory");
 
@@ -224,13 +223,12 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
     }
   };
 
-  f4 acc[TC][TP], accx[TC][TP];
+  f4 acc[TC][TP];
 #pragma unroll
   for (int a = 0; a < TC; ++a)
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
       acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-      accx[a][b] = f4{0.f, 0.f, 0.f, 0.f};
     }
   const int frow = lane & 15;
   const int fgrp = lane >> 4;
@@ -263,11 +261,11 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
 #pragma unroll
     for (int a = 0; a < TC; ++a)
 #pragma unroll
-      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(ah[a], bl[b], accx[a][b]);
+      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bl[b], acc[a][b]);
 #pragma unroll
     for (int a = 0; a < TC; ++a)
 #pragma unroll
-      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(al[a], bh[b], accx[a][b]);
+      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(al[a], bh[b], acc[a][b]);
   };
 
   // ---- pipeline: step q = chunk * NTAPS + tap, weights of step q in ring stage q % 3 ----
@@ -370,7 +368,7 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   };
   auto chanfn = [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; };
   auto valfn = [&](auto ai, auto bi) PP_INLINE_LAMBDA {
-    return acc[decltype(ai)::value][decltype(bi)::value] + accx[decltype(ai)::value][decltype(bi)::value] * LINV;
+    return acc[decltype(ai)::value][decltype(bi)::value] * p.acc_scale;
   };
   epilogue_any<OT, TC, TP, true>(p, e, smem, wave, lane, c_base + wc * TC * 16, rowfn, chanfn, valfn,
                                  [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {

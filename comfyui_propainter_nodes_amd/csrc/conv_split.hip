@@ -7,11 +7,13 @@ namespace pp {
 // ---------------------------------------------------------------------------------------------------------
 // f32 convolution on the f16 matrix pipe ("split" mode, dtype PP_F32X2).
 //
-// Every f32 operand value v is represented by two f16 terms  v ~= h + l / 2048,  h = f16(v),
-// l = f16((v - h) * 2048)  (22 significand bits; the 2048 keeps l out of the f16 denormal range).  Then
-//     sum_k w x  ~=  sum_k wh xh  +  ( sum_k wh xl + sum_k wl xh ) / 2048        (the wl xl term is < 2^-22)
-// i.e. three v_mfma_f32_16x16x32_f16 (16x the f32 MFMA rate each) into two fp32 accumulator sets instead of
-// sixteen v_mfma_f32_32x32x2_f32 steps: the same result to fp32 rounding noise, for |v| < 32752.
+// Every f32 operand value v is represented by two f16 terms  v ~= h + l,  h = f16_rtz(v), l = f16_rtz(v - h)
+// (>= 20 significand bits worst case, 22 typical; r05: the low term is UNSCALED -- the matrix pipe honours f16 subnormals,
+// tools/probes/mfma_denorm.hip; r01-r04 carried l * 2048 and a second accumulator set for the cross terms).  Then
+//     sum_k w x  ~=  sum_k wh xh  +  sum_k wh xl  +  sum_k wl xh        (the wl xl term is < 2^-20 of the sum)
+// i.e. three v_mfma_f32_16x16x32_f16 (16x the f32 MFMA rate each) into ONE fp32 accumulator set instead of sixteen
+// v_mfma_f32_32x32x2_f32 steps.  Constant weights carry a power-of-two scale per layer (ops.split_pack_weight) so that
+// their low terms are normal f16 numbers; the epilogue multiplies the accumulators by its inverse (ConvK::acc_scale).
 //
 // LDS tile row = one 32-channel chunk = 128 bytes = 8 16-byte slots: slots 0-3 the h terms (k 0-31), 4-7 the
 // l terms, slot s stored at s ^ swz(row).  Weights are split on the host (same byte size and chunk
@@ -32,7 +34,6 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
   constexpr int XSTAGE = BP * ROWB, WSTAGE = BCP * ROWB;
   // vector-memory instructions per thread per chunk
   constexpr int NLOADS = WPASS + 2 * XPASS;
-  constexpr float LINV = 1.f / 2048.f;
 
   unsigned char* smem = reinterpret_cast<unsigned char*>(PP_DYN_SMEM);
 
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
     xok[P] = okbits;
     advance();
   };
-  // split the fetched pixels (h: round toward zero, saturating; l: the exact remainder * 2048, round to nearest)
+  // split the fetched pixels (split_pair: h round toward zero, saturating; l: the exact remainder, round toward zero)
   // and write one 16-byte octet per plane
   // `later` = vector-memory instructions this thread issued after the loads of register set P (0 or NLOADS): waiting
   // until only those are outstanding retires, in order, this chunk's weight copies and pixel loads.
@@ -192,13 +193,12 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
     }
   };
 
-  f4 acc[TC][TP], accx[TC][TP];
+  f4 acc[TC][TP];
 #pragma unroll
   for (int a = 0; a < TC; ++a)
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
       acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-      accx[a][b] = f4{0.f, 0.f, 0.f, 0.f};
     }
 
   const int frow = lane & 15;
@@ -228,11 +228,11 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
 #pragma unroll
     for (int a = 0; a < TC; ++a)
 #pragma unroll
-      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(ah[a], bl[b], accx[a][b]);
+      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bl[b], acc[a][b]);
 #pragma unroll
     for (int a = 0; a < TC; ++a)
 #pragma unroll
-      for (int b = 0; b < TP; ++b) accx[a][b] = mfma_16x16x32_f16(al[a], bh[b], accx[a][b]);
+      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(al[a], bh[b], acc[a][b]);
   };
 
   const int nstages = p.nchunks;
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
       },
       [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
       [&](auto ai, auto bi) PP_INLINE_LAMBDA {
-        return acc[decltype(ai)::value][decltype(bi)::value] + accx[decltype(ai)::value][decltype(bi)::value] * LINV;
+        return acc[decltype(ai)::value][decltype(bi)::value] * p.acc_scale;
       },
       [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
         m0 = p_base + wp * TP * 16 + decltype(bi)::value * 16;

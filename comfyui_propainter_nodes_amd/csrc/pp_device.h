@@ -281,6 +281,19 @@ __device__ __forceinline__ h2 cvt_pkrtz_f16(float a, float b) {
 #endif
 }
 
+// The PP_F32X2 operand split of two values (f32 convolutions on the f16 matrix pipe).
+__device__ __forceinline__ void split_pair(float c0, float c1, h2& hh, h2& ll) {
+  // r05: v ~ h + l with h = f16_rtz(v), l = f16_rtz(v - h) UNSCALED: the matrix pipe honours f16 subnormal inputs
+  // (tools/probes/mfma_denorm.hip, measured on the MI355X), so the low term needs no 2^11 scale to survive, the three products of a
+  // multiply-add share one fp32 accumulator (64 registers instead of 128 per wave tile) and the split is 2 vector operations per
+  // value instead of 4 (packed convert, exact fma, packed convert).  Precision: |v - h - l| <= 2^-20 |v| (both conversions
+  // truncate), and never more than 2^-24 absolute below |v| = 2^-4 (the f16 subnormal step); beyond the f16 range h saturates at
+  // 65504 and l at 65504: |v| up to 131008 keeps an absolute error <= 32, larger values saturate -- never Inf / NaN.
+  hh = cvt_pkrtz_f16(c0, c1);
+  const float t0 = __builtin_fmaf((float)hh[0], -1.f, c0), t1 = __builtin_fmaf((float)hh[1], -1.f, c1);
+  ll = cvt_pkrtz_f16(t0, t1);
+}
+
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence
 __device__ __forceinline__ float fast_rcp(float x) {
 #ifdef PP_EMU

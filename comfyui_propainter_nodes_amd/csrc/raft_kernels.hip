@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) im2col_kernel(const TI* __restrict__ in, 
 
 // ----------------------------------------------------------------------------------------
 // PP_F32X2 operand packing of an ACTIVATION matrix that plays the weight role (the all-pairs volume: both operands are
-// feature maps): every 32-float chunk of a row becomes 32 f16 h = f16_rtz(v) followed by 32 f16 l = f16(sat((v-h)*2048)),
+// feature maps): every 32-float chunk of a row becomes 32 f16 h = f16_rtz(v) followed by 32 f16 l = f16_rtz(v - h) (split_pair),
 // the layout pp_conv2d(PP_F32X2) expects for its A operand (host: ops.split_pack_weight).  One thread = 8 values.
 // ----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t total8) {
@@ -77,12 +77,12 @@ __global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict
   h8 h, l;
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
-    const h2 hh = cvt_pkrtz_f16(v[e], v[e + 1]);
+    h2 hh, ll;
+    split_pair(v[e], v[e + 1], hh, ll);
     h[e] = hh[0];
     h[e + 1] = hh[1];
-    const float r0 = (v[e] - (float)hh[0]) * 2048.f, r1 = (v[e + 1] - (float)hh[1]) * 2048.f;
-    l[e] = (half_t)fminf(fmaxf(r0, -65504.f), 65504.f);
-    l[e + 1] = (half_t)fminf(fmaxf(r1, -65504.f), 65504.f);
+    l[e] = ll[0];
+    l[e + 1] = ll[1];
   }
   const int64_t chunk = i >> 2;            // 32-value chunk = 4 octets
   const int oct = (int)(i & 3);

@@ -12,6 +12,7 @@ import threading
 from collections import OrderedDict
 from dataclasses import dataclass
 
+import math
 import os
 
 import torch
@@ -192,14 +193,20 @@ def f32_split_enabled() -> bool:
     return os.environ.get("PP_F32_GEMM", "split").lower() != "exact"
 
 
-def split_pack_weight(packed: torch.Tensor) -> torch.Tensor:
-    """PP_F32X2 weight format: every 32-channel chunk [w0..w31] of an f32 packing becomes 32 f16 `h = f16(w)`
-    followed by 32 f16 `l = f16((w - h) * 2048)`; returned as an f32-typed bit container of the same shape."""
+def split_pack_weight(packed: torch.Tensor) -> tuple[torch.Tensor, float]:
+    """PP_F32X2 weight format (r05): every 32-channel chunk [w0..w31] of an f32 packing becomes 32 f16 `h = f16(S w)` followed by
+    32 f16 `l = f16(S w - h)` -- the low term UNSCALED relative to the high one, so that the three MFMA products of a multiply-add
+    share one accumulator -- with S a power of two per layer that puts max|w| S into [8192, 16384): the low term of every weight
+    that matters is then a normal f16 number (unscaled, the low terms of weights below 0.06 would be subnormal: 2-3 bits lost).
+    Returns (f32-typed bit container of the same shape, acc_scale = 1 / S: exact, applied to the accumulators by the kernel)."""
     cout, kp = packed.shape
     w = packed.float().reshape(cout, kp // 32, 32)
+    wmax = float(w.abs().max())
+    k = 0 if not (wmax > 0.0 and math.isfinite(wmax)) else max(-24, min(24, 13 - math.frexp(wmax)[1] + 1))
+    w = w * (2.0 ** k)
     h = w.clamp(-65504.0, 65504.0).half()
-    l = ((w - h.float()) * 2048.0).clamp(-65504.0, 65504.0).half()  # same saturation as the kernel's split_lo()
-    return torch.cat([h, l], dim=2).contiguous().view(torch.float32).reshape(cout, kp)
+    l = (w - h.float()).clamp(-65504.0, 65504.0).half()
+    return torch.cat([h, l], dim=2).contiguous().view(torch.float32).reshape(cout, kp), 2.0 ** -k
 
 
 @dataclass
@@ -222,6 +229,7 @@ class ConvSpec:
     pad_mode: str = "zeros"
     cin_valid: int = 0            # real (unpadded) input channels per group, for FLOP accounting
     split: bool = False           # f32 tensors on the f16 matrix pipe (PP_F32X2 weight packing)
+    acc_scale: float = 0.0        # PP_F32X2: 1 / (the power-of-two scale inside the packed weights); 0 = 1
     weight_f32: torch.Tensor | None = None  # Cout <= 4 only: fp32 [tap*chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
 
     def to(self, device) -> "ConvSpec":
@@ -260,10 +268,12 @@ def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, 
     if split:
         if dtype != torch.float32:
             raise TypeError("split packing applies to f32 convolutions only")
-        packed = split_pack_weight(packed)
+        packed, acc_scale = split_pack_weight(packed)
+    else:
+        acc_scale = 0.0
     bias = b.detach().float().contiguous() if b is not None else None
     return ConvSpec(packed, bias, list(seg_channels), cout // groups, kh, kw, sh, sw, ph, pw, dh, dw, groups, pad_mode,
-                    sum(seg_valid) if seg_valid else cin_g, split, table)
+                    sum(seg_valid) if seg_valid else cin_g, split, acc_scale, table)
 
 
 def _conv2d_params(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
@@ -316,6 +326,7 @@ def _conv2d_params(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor
     P.act = ACT[act]
     P.act2 = ACT[act2]
     P.act_split = act_split
+    P.acc_scale = spec.acc_scale
     P.act_param = act_param
     P.out_scale = out_scale
     P.epi = EPI[epi]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 8
+#define PP_ABI_VERSION 9
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -140,7 +140,9 @@ typedef struct {
                         that consumes F.unfold()'s tap-major patch vectors -- and the kernel gathers the patches itself:
                         conv(x) == linear(unfold(x)) without the unfolded matrix (sparse_transformer.py:413-433: fc2 of the
                         fusion feed-forward reads the folded 40-channel map, 7x7 / stride 3, instead of a 49x copy) */
-  int32_t reserved0;
+  float acc_scale;   /* (ABI v9, PP_F32X2) the accumulators are multiplied by this before the bias is added; 0 = 1.  The packed
+                        weights of a layer carry a power-of-two scale S (ops.split_pack_weight: max|w| S in [8192, 16384), so that
+                        the LOW f16 term of every weight is a normal number) and acc_scale = 1 / S undoes it exactly */
 } pp_conv2d_params;
 
 int32_t pp_conv2d(void* stream, const pp_conv2d_params* p);
@@ -149,7 +151,9 @@ int32_t pp_conv2d(void* stream, const pp_conv2d_params* p);
  * pp_split_pack -- PP_F32X2 packing of an fp32 matrix [rows][K] (K % 32 == 0) that will be the WEIGHT operand of
  * pp_conv2d(PP_F32X2): the all-pairs correlation volume (corr.py:52-60) multiplies two activation tensors, so the
  * packing the host does once for constant weights (ops.split_pack_weight) runs on the device per clip.
- * out: same byte size, every 32-float chunk -> 32 f16 h | 32 f16 l.
+ * out: same byte size, every 32-float chunk -> 32 f16 h = f16_rtz(v) | 32 f16 l = f16_rtz(v - h)  (r05: the low term is
+ * UNSCALED -- the matrix pipe honours f16 subnormals, tools/probes/mfma_denorm.hip -- so all three products of a
+ * multiply-add, wh xh + wh xl + wl xh, go to ONE fp32 accumulator).
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const void* in;

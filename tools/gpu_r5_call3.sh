@@ -10,5 +10,5 @@ timeout 120 tools/convbench raft_gru_1x5_f32x2 raft_gru128_5x1_f32x2 raft_convc2
 cp $L /tmp/product.so; cp tools/variants/trace.so $L
 timeout 60 tools/convbench raft_gru_1x5_f32x2 raft_convc2_f32x2 raft_fh1_f32x2 2>&1 | grep halo_trace | tee $O/halo_trace.log
 cp /tmp/product.so $L
-timeout 900 python -m pytest tests/test_conv.py tests/test_sample_kernels.py tests/test_raft.py tests/test_rfc.py tests/test_generator.py -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest.log
+timeout 900 python -m pytest tests/test_conv.py tests/test_sample_kernels.py tests/test_raft.py tests/test_raft_kernels.py tests/test_rfc.py tests/test_generator.py tests/test_abi.py -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest.log
 timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>$O/bench.err | grep "^{" | tail -1 > $O/bench.json; python -c "import json,sys;b=json.load(open('$O/bench.json'));print(b['value'], b['ms_per_step'], 'enqueue', b['host_enqueue_ms'], b['roofline']['frac'], b['roofline']['other'], b['parity']['psnr_db'], b['parity']['max_lsb'], b['parity']['flow_max_px'], b['node_call_frames_per_s'])" 2>&1 | tee $O/bench_summary.log
