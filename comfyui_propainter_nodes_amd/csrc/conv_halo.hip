@@ -56,8 +56,7 @@ constexpr bool kHaloTrim64 = false;
 // Phase trace (tools/trace_halo.sh, -DPP_HALO_TRACE; not defined in the product build): every wave accumulates, in scalar
 // registers, the s_memtime ticks it spends per tap in (issue = weight / pixel copies issued) (compute = fragment reads + MFMAs)
 // (close = counted waits + barrier [+ split / store of the next pixel tile at the last tap of a chunk]) and writes the sums behind
-// the epilogue -- no store and no extra wait inside the loop, so the counted vmcnt waits are untouched.  -DPP_HALO_WMID issues
-// the weight copies of step q + 2 in the middle of step q's MFMAs instead of in front of its fragment reads.
+// the epilogue -- no store and no extra wait inside the loop, so the counted vmcnt waits are untouched.
 #ifdef PP_HALO_TRACE
 #define PP_TR_NOW(v)                        \
   __builtin_amdgcn_sched_barrier(0);        \
@@ -65,11 +64,6 @@ constexpr bool kHaloTrim64 = false;
   __builtin_amdgcn_sched_barrier(0)
 #else
 #define PP_TR_NOW(v)
-#endif
-#ifdef PP_HALO_WMID
-constexpr bool kHaloWMid = true;
-#else
-constexpr bool kHaloWMid = false;
 #endif
 
 template <int WC, int WP, int TC, int TP, int KH, int KW>
@@ -237,103 +231,137 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   const unsigned char* wfrag_h = smem + XBYTES + (wc * TC * 16 + frow) * ROWB + ((fgrp ^ swz(frow)) << 4);
   const unsigned char* wfrag_l = smem + XBYTES + (wc * TC * 16 + frow) * ROWB + (((fgrp + 4) ^ swz(frow)) << 4);
 
-  auto compute = [&](auto tapc, int wbuf, auto&& mid) PP_INLINE_LAMBDA {
-    constexpr int tap = decltype(tapc)::value;
-    constexpr int tapoff = (tap / KW) * HW + (tap % KW);
-    const unsigned char* wh = wfrag_h + wbuf * WSTAGE;
-    const unsigned char* wl = wfrag_l + wbuf * WSTAGE;
-    h8 ah[TC], al[TC], bh[TP], bl[TP];
+  // ---- software-pipelined steps (r05) -----------------------------------------------------------------------------------
+  // Step q = chunk * NTAPS + tap; its weights live in ring stage q % 3.  r02-r04 ran every step as copy issue -> fragment reads ->
+  // wait -> 48 MFMAs -> waits -> barrier; the s_memtime phase trace (profiles/r05_f32x2_phase_trace.md) shows what that costs a wave
+  // that has the SIMD to itself: 342 ticks of copy issue + 1038 of reads and MFMAs (768 of them matrix work) + 92 of closing waits
+  // = 1472 per 768, and 1786 when two such waves share a SIMD (1536 would be the matrix pipe's own time).  Now the fragments of
+  // step q are IN REGISTERS when the step begins (loaded during step q - 1), the step issues its three products group by group,
+  // and behind each group the fragments of step q + 1 replace the operands that just died:
+  //     G1  acc += ah x bl   | the copies of step q + 3 (into the stage step q just vacated), the next chunk's pixel fetch,
+  //                          | and at a chunk's last tap the split + store of the next pixel tile (+ one extra barrier)
+  //     G2  acc += al x bh   | <- bl of step q + 1 (pixel tile)
+  //     G3  acc += ah x bh   | <- al of step q + 1 (weights, stage (q + 1) % 3: landed and published by the barrier of step q - 1)
+  //     tail                 | <- ah, bh of step q + 1; counted wait for the weights of step q + 2; barrier
+  // so no MFMA of a step waits for LDS or for a copy, the live fragment registers never exceed one step's 16, and with ONE
+  // accumulator set (64 registers) the wave tile still fits the 256 registers of two work-groups per CU.  A ring stage is
+  // restaged one barrier after its last fragment read retired (pp_barrier: lgkmcnt(0) first) -- the r04 rule.
+  h8 ah[TC], al[TC], bh[TP], bl[TP];
+  auto read_ah = [&](int wbuf) PP_INLINE_LAMBDA {
 #pragma unroll
-    for (int a = 0; a < TC; ++a) {
-      ah[a] = lds_frag(wh + a * 16 * ROWB);
-      al[a] = lds_frag(wl + a * 16 * ROWB);
-    }
-#pragma unroll
-    for (int b = 0; b < TP; ++b) {
-      bh[b] = lds_frag(xfrag + (b * HW + tapoff) * XP);
-      bl[b] = lds_frag(xfrag + (b * HW + tapoff) * XP + 64);
-    }
-#pragma unroll
-    for (int a = 0; a < TC; ++a)
-#pragma unroll
-      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bh[b], acc[a][b]);
-    mid();
-#pragma unroll
-    for (int a = 0; a < TC; ++a)
-#pragma unroll
-      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bl[b], acc[a][b]);
-#pragma unroll
-    for (int a = 0; a < TC; ++a)
-#pragma unroll
-      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(al[a], bh[b], acc[a][b]);
+    for (int a = 0; a < TC; ++a) ah[a] = lds_frag(wfrag_h + wbuf * WSTAGE + a * 16 * ROWB);
   };
+  auto read_al = [&](int wbuf) PP_INLINE_LAMBDA {
+#pragma unroll
+    for (int a = 0; a < TC; ++a) al[a] = lds_frag(wfrag_l + wbuf * WSTAGE + a * 16 * ROWB);
+  };
+  auto read_bh = [&](auto tapc) PP_INLINE_LAMBDA {
+    constexpr int tapoff = (decltype(tapc)::value / KW) * HW + (decltype(tapc)::value % KW);
+#pragma unroll
+    for (int b = 0; b < TP; ++b) bh[b] = lds_frag(xfrag + (b * HW + tapoff) * XP);
+  };
+  auto read_bl = [&](auto tapc) PP_INLINE_LAMBDA {
+    constexpr int tapoff = (decltype(tapc)::value / KW) * HW + (decltype(tapc)::value % KW);
+#pragma unroll
+    for (int b = 0; b < TP; ++b) bl[b] = lds_frag(xfrag + (b * HW + tapoff) * XP + 64);
+  };
+  typedef std::integral_constant<int, 0> Tap0;
 
-  // ---- pipeline: step q = chunk * NTAPS + tap, weights of step q in ring stage q % 3 ----
+  static_assert(NTAPS >= 3, "three steps of weights are in flight");
   const int nck = p.chunks_per_tap;
   fetch_x();
   fetch_w(0, 0);
-  fetch_w(1, 1);                               // NTAPS >= 2: steps 0 and 1 are taps 0 and 1 of chunk 0
-  wait_vmcnt_hidden<2 * WPASS>();
+  fetch_w(1, 1);
+  fetch_w(2, 2);                               // NTAPS >= 3: steps 0, 1, 2 are taps of chunk 0
+  wait_vmcnt_hidden<3 * WPASS>();              // the pixels
   store_x();
-  wait_vmcnt_hidden<WPASS>();
+  wait_vmcnt_hidden<2 * WPASS>();              // the weights of step 0
   pp_wait_lgkm0();
   pp_barrier();
+  read_ah(0);
+  read_al(0);
+  read_bh(Tap0{});
+  read_bl(Tap0{});
+  wait_vmcnt_hidden<WPASS>();                  // the weights of step 1
+  pp_wait_lgkm0();
+  pp_barrier();                                // ... published; every wave holds step 0's fragments: stage 0 is free
   int w0 = 0;                                  // ring stage of the current step
   PP_TR_NOW(tr_loop0);
 #ifdef PP_HALO_TRACE
   uint32_t tr_prev = tr_loop0;
 #endif
+  constexpr int XF = NTAPS - 3;                // the tap that fetches the next chunk's pixels (to registers)
   for (int chunk = 0; chunk < nck; ++chunk) {
     const bool next_chunk = chunk + 1 < nck;
     static_for<NTAPS>([&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
-      constexpr bool pre_last = tap == NTAPS - 2, last = tap == NTAPS - 1;
-      const int w1 = w0 == 2 ? 0 : w0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;
-      // weights two steps ahead: tap + 2 of this chunk, or tap + 2 - NTAPS of the next one
-      const bool more_w = (tap + 2 < NTAPS) || next_chunk;
-      auto issue_w = [&]() PP_INLINE_LAMBDA {
-        if (more_w) {
-          if constexpr (tap + 2 == NTAPS) w_next_chunk();  // the iterator moves on when the look-ahead crosses the chunk end
-          fetch_w(w2, (tap + 2) % NTAPS);
-        }
-      };
-      if constexpr (!kHaloWMid) issue_w();
-      // the next chunk's pixels are fetched (to registers) at the last-but-one tap: one tap of MFMAs for the loads to land.
-      // (r04 measured issuing them at tap 0 instead -- NTAPS - 1 taps ahead, the counted waits adjusted for the in-order
-      //  retirement: 309.2 vs 311.4 TF/s over the family on the whole clip, inside the noise: the chunk boundary's cost is
-      //  not the latency of these loads.)
-      constexpr int XF = NTAPS - 2;
+      constexpr bool last = tap == NTAPS - 1;
+      typedef std::integral_constant<int, (tap + 1) % NTAPS> NextTap;
+      const int w1 = w0 == 2 ? 0 : w0 + 1;
+      const bool has3 = (tap + 3 < NTAPS) || next_chunk;   // step q + 3 exists
+      const bool has1 = !last || next_chunk;               // step q + 1 exists
+      // ---- G1
       if constexpr (tap == XF) {
-        if (next_chunk) fetch_x();
+        if (next_chunk) fetch_x();             // (queue: in front of this step's copies)
       }
-      PP_TR_NOW(tr_a);
-      compute(tapc, w0, [&]() PP_INLINE_LAMBDA {
-        if constexpr (kHaloWMid) {
+      if (has3) {
+        if constexpr (tap + 3 == NTAPS) w_next_chunk();    // the iterator moves on when the look-ahead crosses the chunk end
+        fetch_w(w0, (tap + 3) % NTAPS);
+      }
+      if constexpr (last) {
+        // the next chunk's pixel tile replaces this one: every wave's last reads of it (step q's own bh / bl, issued in step
+        // q - 1) retired before the barrier that closed step q - 1; the pixels were fetched three taps ago and the counted wait
+        // of tap XF + 1 retired them
+        if (next_chunk) store_x();
+      }
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bl[b], acc[a][b]);
 #ifndef PP_EMU
-          __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
 #endif
-          issue_w();
-#ifndef PP_EMU
-          __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-      });
-      PP_TR_NOW(tr_b);
       if constexpr (last) {
         if (next_chunk) {
           pp_wait_lgkm0();
-          pp_barrier();                        // every wave has read its last fragments of the current pixel tile
-          wait_vmcnt_hidden<WPASS>();          // queue: [weights q+1] [pixels] [weights q+2]: retire up to the pixels
-          store_x();
-        } else {
-          wait_vmcnt_hidden<0>();
+          pp_barrier();                        // the new pixel tile is complete
         }
-      } else if constexpr (tap == XF || tap == XF + 1) {
-        // queue after tap XF: [weights q+1] [weights q+2] [pixels]; after tap XF + 1: [weights q+2] [pixels] [weights q+3]:
-        // the weights of the next step must have landed, the pixels and the newest weights may stay in flight
-        if (next_chunk) wait_vmcnt_hidden<WPASS + NX>(); else if (more_w) wait_vmcnt_hidden<WPASS>(); else wait_vmcnt_hidden<0>();
+      }
+      PP_TR_NOW(tr_a);
+      // ---- G2
+      if (has1) read_bl(NextTap{});
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(al[a], bh[b], acc[a][b]);
+#ifndef PP_EMU
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      // ---- G3
+      if (has1) read_al(w1);
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bh[b], acc[a][b]);
+#ifndef PP_EMU
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      PP_TR_NOW(tr_b);
+      // ---- tail
+      if (has1) {
+        read_ah(w1);
+        read_bh(NextTap{});
+      }
+      // the weights of step q + 2 must have landed; this step's copies (step q + 3) and, at tap XF, the pixel fetch issued in
+      // front of them may stay in flight (the queue retires in order: one tap later the pixels are through as well)
+      if (has3) {
+        if constexpr (tap == XF) {
+          if (next_chunk) wait_vmcnt_hidden<WPASS + NX>(); else wait_vmcnt_hidden<WPASS>();
+        } else {
+          wait_vmcnt_hidden<WPASS>();
+        }
       } else {
-        if (more_w) wait_vmcnt_hidden<WPASS>(); else wait_vmcnt_hidden<0>();
+        wait_vmcnt_hidden<0>();
       }
       pp_wait_lgkm0();
       pp_barrier();

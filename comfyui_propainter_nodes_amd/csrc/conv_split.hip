@@ -220,11 +220,9 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
       bh[b] = lds_frag(xs + b * 16 * ROWB + roff_h);
       bl[b] = lds_frag(xs + b * 16 * ROWB + roff_l);
     }
-    // three sweeps over the tile grid: two MFMAs on one accumulator are always TC*TP instructions apart
-#pragma unroll
-    for (int a = 0; a < TC; ++a)
-#pragma unroll
-      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bh[b], acc[a][b]);
+    // three sweeps over the tile grid: two MFMAs on one accumulator are always TC*TP instructions apart.  Product order
+    // (high x low, low x high, high x high) = the halo kernel's (conv_halo.hip frees the operands of a step in that order): the two
+    // kernels sum every accumulator in the same order, i.e. bit-identical results.
 #pragma unroll
     for (int a = 0; a < TC; ++a)
 #pragma unroll
@@ -233,6 +231,10 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
     for (int a = 0; a < TC; ++a)
 #pragma unroll
       for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(al[a], bh[b], acc[a][b]);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) acc[a][b] = mfma_16x16x32_f16(ah[a], bh[b], acc[a][b]);
   };
 
   const int nstages = p.nchunks;
