@@ -418,32 +418,40 @@ __device__ __forceinline__ f4 act4_ct(f4 v, int act_rt, float param) {
   }
 }
 
-// One variant of the LDS-transposed epilogue.  ACT / ACT2 / EPI / PRE: compile-time activation of the channels below / from
-// p.act_split, the fused op and whether a pre-activation addend exists (ACT2 = -2: the launch has no activation split; ACT = -1:
-// everything decided at run time -- the catch-all variant).
-// Why variants, and why the order of the memory operations below (r05, profiles/r05_f32x2_phase_trace.md): the phase trace put
-// the epilogue of a PP_F32X2 halo work-group at 14 000 of its 101 000 cycles on a layer whose epilogue is ONE ReLU and 16 stores
-// per wave.  Neither the stores' coalescing (this transposition alone: same time) nor the instruction count explains ~850 cycles
-// per store; vmcnt does: on gfx9 stores count in vmcnt like loads, so the `s_waitcnt vmcnt` in front of the first use of ANY load
-// issued after a store also waits for that store's write acknowledgement -- and the r02-r04 epilogue loaded bias / aux / pre per
-// quad between the stores (with run-time switches the compiler even waits where no load was issued: the if-converted use needs
-// the wait).  Here no wait for a load ever has an older store in front of it: the bias quad of a lane is loaded once before the
-// first store, the loads of quad row b + 1 are issued BEFORE the stores of row b (the counted wait then leaves those stores in
-// flight), and a variant without aux / pre tensors has no load in its loop at all.
-template <typename OT, int NA, int NB, int ACT, int ACT2, int EPI, int PRE, typename Row0Fn, typename ValFn>
+// One variant of the LDS-transposed epilogue.  ACT / ACT2 / EPI / PRE / OSC: compile-time activation of the channels below /
+// from p.act_split, the fused op, whether a pre-activation addend exists and whether out_scale applies (ACT2 = -2: the launch has
+// no activation split; ACT = -1: everything decided at run time -- the catch-all variant).
+//
+// What the r05 measurements say an epilogue costs (profiles/r05_f32x2_phase_trace.md): 10-15 000 of a PP_F32X2 halo work-group's
+// ~100 000 cycles, for 16 stores per wave.  Not the stores (tools/probes/store_rate: a wave issues 16 KB in ~700 cycles next to a
+// loaded chip; coalescing them changed nothing), not instruction fetch (variants: same time), only partly vmcnt (stores count in
+// vmcnt on gfx9, so a load's wait behind a store waits for its write acknowledgement: -3 000 cycles once no load follows a store).
+// The stamps inside the epilogue show ~2 500 cycles per quad ROW, 1 500 when the wave has the SIMD to itself: the ~200 vector-ALU
+// instructions of a row each wait for a gap between the MFMAs of the work-group that shares the SIMD (one every 16 cycles) -- next to
+// a matrix-bound partner a plain VALU instruction costs about as much as an MFMA.  So this form is written for INSTRUCTION COUNT:
+//   * addresses: a scalar row base (64-bit SALU) + per-lane 32-bit byte offsets computed ONCE (pixel and channel quad of a lane
+//     never change): a store / aux load is one instruction with no address arithmetic (r02-r04: ~6 VALU of 64-bit math per access);
+//   * accumulator scale and bias are ONE fma per element (exact: the scale is a power of two); a launch without bias adds -0.0,
+//     which changes no bit; run-time switches (bias, pre, out_scale) are compile-time or scalar, never per-lane selects;
+//   * whole rows (all 16 pixels inside the image, all channels below Cout) take a path without any per-lane predicate.
+// No wait for a load ever has an older store in front of it: bias quads are loaded once before the first store, the loads of quad
+// row b + 1 are issued BEFORE the stores of row b, and a variant without aux / pre tensors has no load in its loop.
+template <typename OT, int NA, int NB, bool SCALED, int ACT, int ACT2, int EPI, int PRE, int OSC, typename Row0Fn, typename ValFn>
 __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
                                                      Row0Fn row0, ValFn val) {
   constexpr int PITCH = epi_lds_pitch<NA>();
   constexpr int QPR = NA * 4;              // quads per staged pixel
   constexpr bool RT = ACT < 0;             // the run-time variant
   const int frow = lane & 15, fgrp = lane >> 4;
-  const bool has_bias = e.bias != nullptr;
   const bool has_pre = RT ? e.pre != nullptr : PRE != 0;
+  const bool has_osc = RT ? p.out_scale != 0.f : OSC != 0;
   const int epi = RT ? p.epi : EPI;
   const int cmax = p.Cout - 4;             // (fast form: Cout % 4 == 0) loads of a lane past Cout are clamped, its stores masked
-  // per-lane constants of the transposed layout: quad i of a row is pixel px[i], channel quad qq[i]
+  const float sc = SCALED ? p.acc_scale : 1.f;   // (PP_F32X2 kernels hand over RAW accumulators: ConvK::acc_scale)
+  // per-lane constants of the transposed layout: quad i of a row is pixel px[i], channel quad cc[i]
   int cc[NA], px[NA];
-  bool cok[NA];
+  bool cok[NA], second[NA], from[NA];
+  uint32_t o_out[NA], o_a1[NA], o_a2[NA], o_pre[NA], lrd[NA];
   f4 bq[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -452,28 +460,88 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     const int c = c_wave + (q - px[i] * QPR) * 4;
     cok[i] = c < p.Cout;
     cc[i] = c < cmax ? c : cmax;
-    bq[i] = f4{0.f, 0.f, 0.f, 0.f};
-    if (has_bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
+    second[i] = ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split;
+    from[i] = cc[i] >= p.epi_from;
+    const int ce = from[i] ? cc[i] - p.epi_from : 0;
+    o_out[i] = (uint32_t)(px[i] * p.out_ldc + cc[i]) * (uint32_t)sizeof(OT);
+    o_a1[i] = (uint32_t)(px[i] * p.aux1_ldc + ce) * (uint32_t)sizeof(OT);
+    o_a2[i] = (uint32_t)(px[i] * p.aux2_ldc + ce) * (uint32_t)sizeof(OT);
+    o_pre[i] = (uint32_t)(px[i] * p.pre_add_ldc + cc[i]) * (uint32_t)sizeof(OT);
+    lrd[i] = (uint32_t)(px[i] * PITCH + (q - px[i] * QPR) * 16);
+    bq[i] = f4{-0.f, -0.f, -0.f, -0.f};    // (x * sc + -0.0 == x * sc bit for bit)
+    if (e.bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
   }
+  const bool full_c = c_wave + NA * 16 <= p.Cout;   // (uniform) every channel quad of the wave tile exists
   struct RowLd {
     f4 a1[NA], a2[NA], pr[NA];
-    int64_t mm[NA];
+    int64_t m0;
     int nvalid;
   };
   RowLd rl[2];
+  auto ldq = [&](const OT* base, uint32_t off) PP_INLINE_LAMBDA {
+    return load_quad_vec(reinterpret_cast<const OT*>(reinterpret_cast<const char*>(base) + off));
+  };
   auto issue_row = [&](auto bi, RowLd& r) PP_INLINE_LAMBDA {
-    int64_t m0;
-    row0(bi, m0, r.nvalid);
+    row0(bi, r.m0, r.nvalid);
+    if (!has_pre && epi == PP_EPI_NONE) return;
+    const OT* bp = e.pre + r.m0 * p.pre_add_ldc;
+    const OT* b1 = e.aux1 + r.m0 * p.aux1_ldc;
+    const OT* b2 = e.aux2 + r.m0 * p.aux2_ldc;
+    if (r.nvalid >= 16) {                  // (uniform) every pixel of the row exists: no predicate
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      // (addresses clamped into the tensors: a load never needs a branch; rows / pixels that do not exist are masked at the store)
-      r.mm[i] = r.nvalid > 0 ? m0 + (px[i] < r.nvalid ? px[i] : r.nvalid - 1) : 0;
-      if (has_pre) r.pr[i] = load_quad_vec(e.pre + r.mm[i] * p.pre_add_ldc + cc[i]);
-      if (epi != PP_EPI_NONE) {
-        const int ce = cc[i] >= p.epi_from ? cc[i] - p.epi_from : 0;
-        r.a1[i] = load_quad_vec(e.aux1 + r.mm[i] * p.aux1_ldc + ce);
-        if (epi == PP_EPI_GRU) r.a2[i] = load_quad_vec(e.aux2 + r.mm[i] * p.aux2_ldc + ce);
+      for (int i = 0; i < NA; ++i) {
+        if (has_pre) r.pr[i] = ldq(bp, o_pre[i]);
+        if (epi != PP_EPI_NONE) r.a1[i] = ldq(b1, o_a1[i]);
+        if (epi == PP_EPI_GRU) r.a2[i] = ldq(b2, o_a2[i]);
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        r.pr[i] = r.a1[i] = r.a2[i] = f4{0.f, 0.f, 0.f, 0.f};
+        if (px[i] < r.nvalid) {
+          if (has_pre) r.pr[i] = ldq(bp, o_pre[i]);
+          if (epi != PP_EPI_NONE) r.a1[i] = ldq(b1, o_a1[i]);
+          if (epi == PP_EPI_GRU) r.a2[i] = ldq(b2, o_a2[i]);
+        }
+      }
+    }
+  };
+  // store_quad_fast()'s arithmetic on one quad, operation by operation (acc * sc + bias as one fma: sc is a power of two)
+  auto finish = [&](f4 x, int i, const RowLd& r) PP_INLINE_LAMBDA {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = __builtin_fmaf(x[k], sc, bq[i][k]);
+    if (has_pre) x += r.pr[i];
+    if (second[i]) {
+      x = act4_ct<ACT2>(x, p.act2, p.act_param);
+    } else {
+      x = act4_ct<ACT>(x, p.act, p.act_param);
+      if (has_osc) x *= p.out_scale;
+    }
+    if (epi != PP_EPI_NONE && from[i]) {
+      if (epi == PP_EPI_MUL_AUX1) {
+        x *= r.a1[i];
+      } else if (epi == PP_EPI_ADD_AUX1) {
+        x += r.a1[i];
+      } else if (epi == PP_EPI_ADD_AUX1_RELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float t = x[k] + r.a1[i][k];
+          x[k] = t > 0.f ? t : 0.f;
+        }
+      } else if (epi == PP_EPI_GRU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = (1.f - r.a1[i][k]) * r.a2[i][k] + r.a1[i][k] * x[k];
+      }
+    }
+    return x;
+  };
+  auto put = [&](OT* rowp, uint32_t off, f4 x) PP_INLINE_LAMBDA {
+    OT* dst = reinterpret_cast<OT*>(reinterpret_cast<char*>(rowp) + off);
+    if constexpr (sizeof(OT) == 2) {
+      h4 o = {sat_half(x[0]), sat_half(x[1]), sat_half(x[2]), sat_half(x[3])};
+      *reinterpret_cast<h4*>(dst) = o;
+    } else {
+      *reinterpret_cast<f4*>(dst) = x;
     }
   };
   PP_EPI_STAMP(e, 1);
@@ -488,56 +556,17 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     pp_wave_lds_fence();
     f4 v[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) v[i] = *reinterpret_cast<const f4*>(wlds + px[i] * PITCH + (i * 64 + lane - px[i] * QPR) * 16);
+    for (int i = 0; i < NA; ++i) v[i] = *reinterpret_cast<const f4*>(wlds + lrd[i]);
     if constexpr (b + 1 < NB) issue_row(std::integral_constant<int, b + 1>{}, rl[(b + 1) & 1]);  // before this row's stores
-    // the arithmetic of store_quad_fast(), operation by operation
+    OT* rowp = e.out + r.m0 * p.out_ldc;
+    if (r.nvalid >= 16 && full_c) {        // (uniform) the whole row is stored: no predicate
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      f4 x = v[i];
-      if (has_bias) x += bq[i];
-      if (has_pre) x += r.pr[i];
-      if (ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split) {
-        x = act4_ct<ACT2>(x, p.act2, p.act_param);
-      } else {
-        x = act4_ct<ACT>(x, p.act, p.act_param);
-        if (p.out_scale != 0.f) x *= p.out_scale;
-      }
-      if (epi != PP_EPI_NONE && cc[i] >= p.epi_from) {
-        if (epi == PP_EPI_MUL_AUX1) {
-          x *= r.a1[i];
-        } else if (epi == PP_EPI_ADD_AUX1) {
-          x += r.a1[i];
-        } else if (epi == PP_EPI_ADD_AUX1_RELU) {
+      for (int i = 0; i < NA; ++i) put(rowp, o_out[i], finish(v[i], i, r));
+    } else if (r.nvalid > 0) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float t = x[k] + r.a1[i][k];
-            x[k] = t > 0.f ? t : 0.f;
-          }
-        } else if (epi == PP_EPI_GRU) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) x[k] = (1.f - r.a1[i][k]) * r.a2[i][k] + r.a1[i][k] * x[k];
-        }
-      }
-      if (cok[i] && px[i] < r.nvalid) {
-        OT* dst = e.out + r.mm[i] * p.out_ldc + cc[i];
-        if constexpr (sizeof(OT) == 2) {
-          h4 o = {sat_half(x[0]), sat_half(x[1]), sat_half(x[2]), sat_half(x[3])};
-          *reinterpret_cast<h4*>(dst) = o;
-        } else {
-#if defined(PP_EPI_STORE_MODE) && !defined(PP_EMU)   // experiment hook (tools/build_variant.sh): cache policy of the output stores
-#if PP_EPI_STORE_MODE == 1
-          asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(x) : "memory");
-#elif PP_EPI_STORE_MODE == 2
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(x) : "memory");
-#elif PP_EPI_STORE_MODE == 3
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(x) : "memory");
-#elif PP_EPI_STORE_MODE == 4
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(x) : "memory");
-#endif
-#else
-          *reinterpret_cast<f4*>(dst) = x;
-#endif
-        }
+      for (int i = 0; i < NA; ++i) {
+        const f4 x = finish(v[i], i, r);
+        if (cok[i] && px[i] < r.nvalid) put(rowp, o_out[i], x);
       }
     }
     pp_wave_lds_fence();  // the next row's staging writes come after this row's reads
@@ -545,42 +574,50 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
   });
 }
 
-// Dispatch to the variant of the launch's (act, act2, epi, pre_add): the combinations the pipeline's layers use are compiled in,
-// anything else takes the run-time variant (same arithmetic).
-template <typename OT, int NA, int NB, typename Row0Fn, typename ValFn>
+// Dispatch to the variant of the launch's (act, act2, epi, pre_add, out_scale): the combinations the pipeline's layers use are
+// compiled in, anything else takes the run-time variant (same arithmetic).
+template <typename OT, int NA, int NB, bool SCALED, typename Row0Fn, typename ValFn>
 __device__ __forceinline__ void epilogue_quads_lds(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
                                                    Row0Fn row0, ValFn val) {
   const int a2 = p.act_split > 0 ? p.act2 : -2;
   const int pre = e.pre != nullptr ? 1 : 0;
-#define PP_EPI_VARIANT(A, A2, E, P)                                                                \
-  if (p.act == (A) && a2 == (A2) && p.epi == (E) && pre == (P)) {                                  \
-    epilogue_lds_variant<OT, NA, NB, (A), (A2), (E), (P)>(p, e, wlds, lane, c_wave, row0, val);    \
-    return;                                                                                        \
+  const int osc = p.out_scale != 0.f ? 1 : 0;
+#define PP_EPI_VARIANT(A, A2, E, P, O)                                                                  \
+  if (p.act == (A) && a2 == (A2) && p.epi == (E) && pre == (P) && osc == (O)) {                        \
+    epilogue_lds_variant<OT, NA, NB, SCALED, (A), (A2), (E), (P), (O)>(p, e, wlds, lane, c_wave, row0, val);    \
+    return;                                                                                             \
   }
-  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0)
-  PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_NONE, 0)
-  PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_NONE, 0)
-  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_ADD_AUX1, 0)
-  PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_ADD_AUX1_RELU, 0)
-  PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_ADD_AUX1, 0)
-  PP_EPI_VARIANT(PP_ACT_SIGMOID, -2, PP_EPI_MUL_AUX1, 1)
-  PP_EPI_VARIANT(PP_ACT_TANH, -2, PP_EPI_GRU, 1)
-  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_RELU, PP_EPI_NONE, 0)
-  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_SIGMOID, PP_EPI_NONE, 0)
+  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_NONE, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_NONE, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_ADD_AUX1, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_ADD_AUX1_RELU, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_ADD_AUX1, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_SIGMOID, -2, PP_EPI_MUL_AUX1, 1, 0)
+  PP_EPI_VARIANT(PP_ACT_TANH, -2, PP_EPI_GRU, 1, 0)
+  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_RELU, PP_EPI_NONE, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_SIGMOID, PP_EPI_NONE, 0, 1)
+  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 1)
 #undef PP_EPI_VARIANT
-  epilogue_lds_variant<OT, NA, NB, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
+  epilogue_lds_variant<OT, NA, NB, SCALED, -1, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
 }
 
 // One epilogue entry for every convolution kernel: the general form when the launch's views are not vector-aligned, the
 // LDS-transposed form when the work-group's LDS holds the waves' staging rows (FITS, a compile-time fact of the launcher's LDS
 // size) and PP_CONV_EPI is not "direct", else the direct fast form.  `smem` = the work-group's dynamic LDS: every wave must be done
 // with it (the barrier below) and no LDS-DMA copy may be in flight (vmcnt).
-template <typename OT, int NA, int NB, bool FITS, bool BARRIER = true, typename RowFn, typename ChanFn, typename ValFn, typename Row0Fn>
+template <typename OT, int NA, int NB, bool FITS, bool BARRIER = true, bool SCALED = false, typename RowFn, typename ChanFn,
+          typename ValFn, typename Row0Fn>
 __device__ __forceinline__ void epilogue_any(const ConvK& p, const EpiCtx<OT>& e, unsigned char* smem, int wave, int lane, int c_wave,
                                              RowFn row, ChanFn chan, ValFn val, Row0Fn row0) {
+  // SCALED (the PP_F32X2 kernels): val() returns RAW accumulators, to be multiplied by ConvK::acc_scale before the bias
+  auto val_s = [&](auto ai, auto bi) PP_INLINE_LAMBDA {
+    if constexpr (SCALED) return val(ai, bi) * p.acc_scale;
+    else return val(ai, bi);
+  };
   if constexpr (FITS) {
     if (!epi_fast_ok<OT>(p, e) || !p.epi_lds) {   // odd views, or PP_CONV_EPI=direct (A/B: same bits)
-      epilogue_quads_general<OT, NA, NB>(p, e, row, chan, val);
+      epilogue_quads_general<OT, NA, NB>(p, e, row, chan, val_s);
       return;
     }
     if constexpr (BARRIER) {   // (false: the caller hands over LDS no other wave touches any more)
@@ -588,9 +625,9 @@ __device__ __forceinline__ void epilogue_any(const ConvK& p, const EpiCtx<OT>& e
       pp_barrier();
     }
     PP_EPI_STAMP(e, 0);
-    epilogue_quads_lds<OT, NA, NB>(p, e, smem + wave * epi_lds_wave_bytes<NA>(), lane, c_wave, row0, val);
+    epilogue_quads_lds<OT, NA, NB, SCALED>(p, e, smem + wave * epi_lds_wave_bytes<NA>(), lane, c_wave, row0, val);
   } else {
-    epilogue_quads<OT, NA, NB>(p, e, row, chan, val);
+    epilogue_quads<OT, NA, NB>(p, e, row, chan, val_s);
   }
 }
 

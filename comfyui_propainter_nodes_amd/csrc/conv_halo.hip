@@ -396,9 +396,9 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   };
   auto chanfn = [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; };
   auto valfn = [&](auto ai, auto bi) PP_INLINE_LAMBDA {
-    return acc[decltype(ai)::value][decltype(bi)::value] * p.acc_scale;
+    return acc[decltype(ai)::value][decltype(bi)::value];
   };
-  epilogue_any<OT, TC, TP, true>(p, e, smem, wave, lane, c_base + wc * TC * 16, rowfn, chanfn, valfn,
+  epilogue_any<OT, TC, TP, true, true, true>(p, e, smem, wave, lane, c_base + wc * TC * 16, rowfn, chanfn, valfn,
                                  [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
                                    const int oy = ty0 + wp * TP + decltype(bi)::value;
                                    m0 = ((int64_t)n * p.Ho + oy) * p.Wo + tx0;

@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
   e.aux2 = p.aux2 ? reinterpret_cast<const OT*>(p.aux2) + (int64_t)z * p.aux2_zoff : nullptr;
   e.pre = reinterpret_cast<const OT*>(p.pre_add);
   constexpr bool EPI_FITS = WC * WP * epi_lds_wave_bytes<TC>() <= 2 * XSTAGE + 3 * WSTAGE;
-  epilogue_any<OT, TC, TP, EPI_FITS>(
+  epilogue_any<OT, TC, TP, EPI_FITS, true, true>(
       p, e, smem, wave, lane, c_base + wc * TC * 16,
       [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
         m = p_base + wp * TP * 16 + decltype(bi)::value * 16 + frow;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(WC * WP * 64, 2) conv_split_kernel(const ConvK
       },
       [&](auto ai) PP_INLINE_LAMBDA { return c_base + wc * TC * 16 + decltype(ai)::value * 16 + fgrp * 4; },
       [&](auto ai, auto bi) PP_INLINE_LAMBDA {
-        return acc[decltype(ai)::value][decltype(bi)::value] * p.acc_scale;
+        return acc[decltype(ai)::value][decltype(bi)::value];
       },
       [&](auto bi, int64_t& m0, int& nvalid) PP_INLINE_LAMBDA {
         m0 = p_base + wp * TP * 16 + decltype(bi)::value * 16;
