@@ -436,7 +436,9 @@ __device__ __forceinline__ f4 act4_ct(f4 v, int act_rt, float param) {
 //   * whole rows (all 16 pixels inside the image, all channels below Cout) take a path without any per-lane predicate.
 // No wait for a load ever has an older store in front of it: bias quads are loaded once before the first store, the loads of quad
 // row b + 1 are issued BEFORE the stores of row b, and a variant without aux / pre tensors has no load in its loop.
-template <typename OT, int NA, int NB, bool SCALED, int ACT, int ACT2, int EPI, int PRE, int OSC, typename Row0Fn, typename ValFn>
+// LDS = false: the same epilogue on the quads as the MFMA leaves them (a lane keeps its pixel column, its NA quads are 16 channels
+// apart): no staging, used where the LDS round trips cost more than they save (short-reduction GEMMs).
+template <typename OT, int NA, int NB, bool SCALED, bool LDS, int ACT, int ACT2, int EPI, int PRE, int OSC, typename Row0Fn, typename ValFn>
 __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
                                                      Row0Fn row0, ValFn val) {
   constexpr int PITCH = epi_lds_pitch<NA>();
@@ -456,8 +458,8 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int q = i * 64 + lane;
-    px[i] = q / QPR;
-    const int c = c_wave + (q - px[i] * QPR) * 4;
+    px[i] = LDS ? q / QPR : frow;
+    const int c = LDS ? c_wave + (q - px[i] * QPR) * 4 : c_wave + i * 16 + fgrp * 4;
     cok[i] = c < p.Cout;
     cc[i] = c < cmax ? c : cmax;
     second[i] = ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split;
@@ -467,7 +469,7 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     o_a1[i] = (uint32_t)(px[i] * p.aux1_ldc + ce) * (uint32_t)sizeof(OT);
     o_a2[i] = (uint32_t)(px[i] * p.aux2_ldc + ce) * (uint32_t)sizeof(OT);
     o_pre[i] = (uint32_t)(px[i] * p.pre_add_ldc + cc[i]) * (uint32_t)sizeof(OT);
-    lrd[i] = (uint32_t)(px[i] * PITCH + (q - px[i] * QPR) * 16);
+    lrd[i] = LDS ? (uint32_t)(px[i] * PITCH + (q - px[i] * QPR) * 16) : 0u;
     bq[i] = f4{-0.f, -0.f, -0.f, -0.f};    // (x * sc + -0.0 == x * sc bit for bit)
     if (e.bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
   }
@@ -550,13 +552,17 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
   static_for<NB>([&](auto bi) {
     constexpr int b = decltype(bi)::value;
     RowLd& r = rl[b & 1];
-    static_for<NA>([&](auto ai) {
-      *reinterpret_cast<f4*>(wlds + frow * PITCH + (decltype(ai)::value * 16 + fgrp * 4) * 4) = val(ai, bi);
-    });
-    pp_wave_lds_fence();
     f4 v[NA];
+    if constexpr (LDS) {
+      static_for<NA>([&](auto ai) {
+        *reinterpret_cast<f4*>(wlds + frow * PITCH + (decltype(ai)::value * 16 + fgrp * 4) * 4) = val(ai, bi);
+      });
+      pp_wave_lds_fence();
 #pragma unroll
-    for (int i = 0; i < NA; ++i) v[i] = *reinterpret_cast<const f4*>(wlds + lrd[i]);
+      for (int i = 0; i < NA; ++i) v[i] = *reinterpret_cast<const f4*>(wlds + lrd[i]);
+    } else {
+      static_for<NA>([&](auto ai) { v[decltype(ai)::value] = val(ai, bi); });
+    }
     if constexpr (b + 1 < NB) issue_row(std::integral_constant<int, b + 1>{}, rl[(b + 1) & 1]);  // before this row's stores
     OT* rowp = e.out + r.m0 * p.out_ldc;
     if (r.nvalid >= 16 && full_c) {        // (uniform) the whole row is stored: no predicate
@@ -569,14 +575,14 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
         if (cok[i] && px[i] < r.nvalid) put(rowp, o_out[i], x);
       }
     }
-    pp_wave_lds_fence();  // the next row's staging writes come after this row's reads
+    if constexpr (LDS) pp_wave_lds_fence();  // the next row's staging writes come after this row's reads
     if constexpr (b < 4) { PP_EPI_STAMP(e, 3 + b); }
   });
 }
 
 // Dispatch to the variant of the launch's (act, act2, epi, pre_add, out_scale): the combinations the pipeline's layers use are
 // compiled in, anything else takes the run-time variant (same arithmetic).
-template <typename OT, int NA, int NB, bool SCALED, typename Row0Fn, typename ValFn>
+template <typename OT, int NA, int NB, bool SCALED, bool LDS, typename Row0Fn, typename ValFn>
 __device__ __forceinline__ void epilogue_quads_lds(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
                                                    Row0Fn row0, ValFn val) {
   const int a2 = p.act_split > 0 ? p.act2 : -2;
@@ -584,7 +590,7 @@ __device__ __forceinline__ void epilogue_quads_lds(const ConvK& p, const EpiCtx<
   const int osc = p.out_scale != 0.f ? 1 : 0;
 #define PP_EPI_VARIANT(A, A2, E, P, O)                                                                  \
   if (p.act == (A) && a2 == (A2) && p.epi == (E) && pre == (P) && osc == (O)) {                        \
-    epilogue_lds_variant<OT, NA, NB, SCALED, (A), (A2), (E), (P), (O)>(p, e, wlds, lane, c_wave, row0, val);    \
+    epilogue_lds_variant<OT, NA, NB, SCALED, LDS, (A), (A2), (E), (P), (O)>(p, e, wlds, lane, c_wave, row0, val);    \
     return;                                                                                             \
   }
   PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 0)
@@ -599,7 +605,7 @@ __device__ __forceinline__ void epilogue_quads_lds(const ConvK& p, const EpiCtx<
   PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_SIGMOID, PP_EPI_NONE, 0, 1)
   PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 1)
 #undef PP_EPI_VARIANT
-  epilogue_lds_variant<OT, NA, NB, SCALED, -1, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
+  epilogue_lds_variant<OT, NA, NB, SCALED, LDS, -1, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
 }
 
 // One epilogue entry for every convolution kernel: the general form when the launch's views are not vector-aligned, the
@@ -625,8 +631,11 @@ __device__ __forceinline__ void epilogue_any(const ConvK& p, const EpiCtx<OT>& e
       pp_barrier();
     }
     PP_EPI_STAMP(e, 0);
-    epilogue_quads_lds<OT, NA, NB, SCALED>(p, e, smem + wave * epi_lds_wave_bytes<NA>(), lane, c_wave, row0, val);
+    epilogue_quads_lds<OT, NA, NB, SCALED, true>(p, e, smem + wave * epi_lds_wave_bytes<NA>(), lane, c_wave, row0, val);
   } else {
+    // (r05: the lean variants on the direct quads -- epilogue_quads_lds<..., LDS = false> -- were measured on the 8-wave GEMM tiles:
+    //  fc1 611 -> 460, qkv 588 -> 464 TF/s.  Those kernels live on 128 registers per wave (two work-groups per CU); the variant's
+    //  row-ahead load buffers do not fit, and the occupancy they cost outweighs the instructions they save.)
     epilogue_quads<OT, NA, NB>(p, e, row, chan, val_s);
   }
 }

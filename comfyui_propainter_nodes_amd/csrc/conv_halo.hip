@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
     unsigned char* wt = smem + XBYTES + wbuf * WSTAGE;
     const char* src = reinterpret_cast<const char*>(wptr + (tap * tapstride + w_sbase + w_rem * 32));
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) glds16(src + (size_t)wlane[i], wt + (i * NT + wave * 64) * 16);
+    for (int i = 0; i < WPASS; ++i) glds16_s(src, wlane[i], wt + (i * NT + wave * 64) * 16);
   };
   auto w_next_chunk = [&]() PP_INLINE_LAMBDA {
     if (++w_rem == w_chunks) {
@@ -193,27 +193,41 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
       }
     }
   };
+  // Next to a matrix-bound partner wave every vector-ALU instruction costs about one MFMA slot (r05 trace), so the split does no
+  // more than it must: a wave's 16 rows of a pass that lie wholly behind the halo tile are skipped, and when every piece the wave
+  // fetched exists (interior tiles, full channel chunks: one ballot per chunk) the zero-fill selects are skipped too.
+  auto split_store = [&](int i, auto masked) PP_INLINE_LAMBDA {
+    f4 v[2] = {xreg[i][0], xreg[i][1]};
+    if constexpr (decltype(masked)::value) {
+      if (!((xok >> (2 * i)) & 1)) v[0] = f4{0.f, 0.f, 0.f, 0.f};
+      if (!((xok >> (2 * i)) & 2)) v[1] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    h8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
+      h2 hh, ll;
+      split_pair(c0, c1, hh, ll);
+      h[e] = hh[0];
+      h[e + 1] = hh[1];
+      l[e] = ll[0];
+      l[e + 1] = ll[1];
+    }
+    unsigned char* rowp = smem + (xrow0 + i * XROWS) * XP + xj * 16;
+    *reinterpret_cast<h8*>(rowp) = h;
+    *reinterpret_cast<h8*>(rowp + 64) = l;
+  };
   auto store_x = [&]() PP_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
       if (kHaloTrim64 && xrow0 + i * XROWS >= HROWS) continue;   // trimmed tile: the rows past the halo tile do not exist
-      f4 v[2] = {xreg[i][0], xreg[i][1]};
-      if (!((xok >> (2 * i)) & 1)) v[0] = f4{0.f, 0.f, 0.f, 0.f};
-      if (!((xok >> (2 * i)) & 2)) v[1] = f4{0.f, 0.f, 0.f, 0.f};
-      h8 h, l;
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const float c0 = v[e >> 2][e & 3], c1 = v[e >> 2][(e & 3) + 1];
-        h2 hh, ll;
-        split_pair(c0, c1, hh, ll);
-        h[e] = hh[0];
-        h[e + 1] = hh[1];
-        l[e] = ll[0];
-        l[e + 1] = ll[1];
-      }
-      unsigned char* rowp = smem + (xrow0 + i * XROWS) * XP + xj * 16;
-      *reinterpret_cast<h8*>(rowp) = h;
-      *reinterpret_cast<h8*>(rowp + 64) = l;
+      if (wave * 16 + i * XROWS >= HROWS) continue;             // (scalar) this wave's rows of the pass are never read
+#ifdef PP_EMU
+      const bool all_ok = false;
+#else
+      const bool all_ok = __builtin_amdgcn_ballot_w64(((xok >> (2 * i)) & 3) != 3) == 0ull;   // (wave-uniform)
+#endif
+      if (all_ok) split_store(i, std::false_type{}); else split_store(i, std::true_type{});
     }
   };
 

@@ -74,6 +74,16 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same copy with a wave-uniform 64-bit base in SGPRs and an unsigned 32-bit per-lane BYTE offset (the instruction's saddr
+// form): no 64-bit per-lane address -- hipcc builds one with a v_lshl_add_u64 per copy from the builtin above, and next to a
+// matrix-bound partner wave a vector-ALU instruction costs about one MFMA slot (r05).  lds_wave_base must be wave-uniform.
+// Not visible to the compiler's vmcnt accounting: for kernels that count their waits by hand (conv_halo.hip).
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, void* lds_wave_base) {
+  const uint32_t m0v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase),
+               "s"(__builtin_amdgcn_readfirstlane(m0v))
+               : "memory", "m0");
+}
 __device__ __attribute__((aligned(16))) const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
 // counted wait on the vector-memory queue (global_load_lds copies are tracked by vmcnt) and a bare barrier that
 // does NOT drain that queue (unlike __syncthreads()), so copies can stay in flight across it
@@ -133,6 +143,9 @@ inline void glds16(const void* g, void* lds_wave_base) {
   memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * pp_emu::cur->lane, g, 16);
 }
 static const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
+inline void glds16_s(const void* sbase, uint32_t voff, void* lds_wave_base) {
+  memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * pp_emu::cur->lane, static_cast<const char*>(sbase) + voff, 16);
+}
 template <int N>
 inline void pp_wait_vmcnt() {}
 inline void pp_wait_lgkm0() {}
