@@ -294,8 +294,8 @@ def main():
         lo, hi = D.frames_needed(D.ShardPlan(T, cfg.subvideo_length, world, rank))
         fr_d = D.Slab(lo, torch.from_numpy(frames_u8[lo:hi]).to(dev))
 
-        def step():
-            return D.run_distributed(backend, cfg, fr_d, fm_d, md_d, gather_root=0)   # only rank 0 returns the clip
+        def step(timeline=None):
+            return D.run_distributed(backend, cfg, fr_d, fm_d, md_d, gather_root=0, timeline=timeline)   # only rank 0 returns the clip
     else:
         fr_d = torch.from_numpy(frames_u8).to(dev)
 
@@ -323,6 +323,25 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     fps = T * args.steps / elapsed
+
+    # ---- N > 1: one extra INSTRUMENTED step (synchronize at every hand-over), every rank's segment clock collected on rank 0, so
+    # that a scaling record can be diagnosed from the line itself: compute between exchanges, what each exchange cost, what a
+    # posted exchange still had to wait for (`p2p_wait`), bytes sent
+    per_rank = None
+    if dist is not None:
+        tl = []
+        fence()
+        step(tl)
+        fence()
+        allt = [None] * world
+        dist.all_gather_object(allt, tl)
+        if rank == 0:
+            per_rank = []
+            for r, segs in enumerate(allt):
+                comp = [ms for k, ms, _ in segs if k == "compute"]
+                exch = [{"kind": k, "ms": ms, "MB_sent": round(b / 1e6, 2)} for k, ms, b in segs if k != "compute"]
+                per_rank.append({"rank": r, "compute_ms": comp, "compute_total_ms": round(sum(comp), 1), "exchanges": exch,
+                                 "exchange_total_ms": round(sum(e["ms"] for e in exch), 1)})
 
     # ---- host side of one step: how long the launching thread needs to ENQUEUE a step (return of step() with no synchronize
     # behind it) -- the budget that matters when N rank threads of one process share the GIL (PP_GPUS=N)
@@ -358,7 +377,10 @@ def main():
                     "traffic": traffic, "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{tfile.name})",
                     "algorithmic_bytes_per_launch": d["bytes"] / d["n"], "launches": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / d["n"], 2),
                     "flops_per_launch": d["flops"] / d["n"], "share_of_step_ms": round(d["ms"], 1),
-                    "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 1), "launches": v["n"]}
+                    "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 1), "launches": v["n"],
+                                  "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS.get(k, PEAK_TFLOPS["f16"]), 4),
+                                  "algorithmic_bytes_per_launch": round(v["bytes"] / max(1, v["n"])),
+                                  "traffic": fam.get(k, {}).get("hbm_bytes_per_launch")}
                               for k, v in prof.items() if k != dom and k not in ("attention", "corr_lookup")}}
         # end-to-end: every MFMA flop of the step priced at its family's nominal peak (PP_F32X2 at 2.5 PF / 3 products), against
         # the wall time of the timed step (the whole step as a fraction of the blended MFMA roofline)
@@ -392,9 +414,18 @@ def main():
         "data": f"synthetic clip (seeded texture + sinusoidal motion, centre box mask); weights: {prov}",
         "config": {"workload": f"{T}-frame 640x360 clip, neighbor_length 10, ref_stride 10, subvideo_length {CFG['subvideo_length']}, raft_iter 20, "
                                f"fp16 enable (BASELINE.json configs[{1 if world == 1 else 3}])", "frames_per_gpu": T // world,
+                   "value_is": "the device-resident pipeline (uint8 frames + masks in HBM when the timed region starts, composed uint8 "
+                               "frames left in HBM: the bench contract); SURVEY 8d's node call-to-return rate, H2D / D2H included, is "
+                               "node_call_frames_per_s on the same line",
                    "parallelism": f"subvideo x{world}" + (" (one clip, seam all_gather over RCCL)" if world > 1 else "")},
         "roofline": roofline,
     }
+    if per_rank is not None:
+        line["per_rank"] = {"what": "one extra step with a device synchronize at every exchange hand-over (not the timed steps): "
+                                    "compute between the exchanges x0 raw-flow halos, x1 completed-flow halos, x2 masks (p2p) + "
+                                    "encoder features (p2p_start / p2p_wait), x3 seam-window outputs (p2p_start / p2p_wait), x4 "
+                                    "composed frames to rank 0 (p2p); p2p_wait = what was left to wait for after the work done "
+                                    "under the posted exchange", "ranks": per_rank}
     if rank == 0 and world == 1 and not args.no_extras:
         line["node_call"] = node_call_timing(dev)
         line["node_call_frames_per_s"] = line["node_call"]["frames_per_s"]   # SURVEY.md 8d's metric (PCIe-inclusive)

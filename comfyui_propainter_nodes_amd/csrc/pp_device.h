@@ -258,12 +258,16 @@ __device__ __forceinline__ float from_f32<float>(float v) {
 // round-to-nearest convert; identity inside the range).  The two learned recurrences run 80-160 dependent steps on f16 tensors:
 // with weights that are not contractive their activations grow geometrically, and one Inf turns into NaN at the next
 // Inf - Inf or 0 x Inf (bilinear blends, residual adds) and then into every pixel downstream.  Saturated values stay finite
-// (r04; tests/test_rfc.py::test_undamped_recurrences_saturate).  NaN inputs do not occur: nothing upstream produces one.
+// (r04; tests/test_rfc.py::test_undamped_recurrences_saturate).  A NaN input stays NaN (r05).
 __device__ __forceinline__ half_t sat_half(float v) {
+  // (v_med3_f32 / fminf(fmaxf()) return a bound for a NaN input, which would turn an upstream NaN bug into a
+  //  plausible -65504.  v_max_f32 / v_min_f32 with IEEE mode on return the OTHER operand only for a quiet NaN in one of them and
+  //  so cannot be used either: select explicitly -- a NaN stays a NaN.)
 #ifdef PP_EMU
-  return (half_t)fminf(fmaxf(v, -65504.f), 65504.f);
+  return v != v ? (half_t)v : (half_t)fminf(fmaxf(v, -65504.f), 65504.f);
 #else
-  return (half_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  const float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  return (half_t)(v != v ? v : c);
 #endif
 }
 template <>

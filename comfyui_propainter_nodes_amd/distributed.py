@@ -409,7 +409,7 @@ def frames_needed(plan: ShardPlan) -> tuple[int, int]:
 # runners
 # ------------------------------------------------------------------------------------------------
 def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8, masks_dilated_u8, group=None,
-                    gather_root: int | None = None):
+                    gather_root: int | None = None, timeline: list | None = None):
     """One rank of a torch.distributed job (backend "nccl" = RCCL on the MI355X, "gloo" in CPU tests).  all_gather for the
     two whole-clip exchanges, grouped point-to-point sends / receives (xGMI is point to point: a seam travels over the one
     link between the two neighbours) for the halos."""
@@ -440,9 +440,29 @@ def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8,
     # PP_P2P_ASYNC=0: complete every posted exchange at once (the blocking form of r02) -- a switch for operators should the
     # overlap of batch_isend_irecv with the compute stream misbehave on some RCCL build; the default keeps exchanges in flight
     blocking = os.environ.get("PP_P2P_ASYNC", "1") == "0"
+    # `timeline` (bench.py --gpus N, one extra instrumented step): this rank's wall clock per segment, with a device synchronize
+    # at every hand-over so that compute and exchange times separate -- [("compute" | kind, milliseconds, bytes sent)], kinds
+    # in the order of the protocol: p2p (x0 raw-flow halos, x1 completed-flow halos, x2 masks), p2p_start / p2p_wait (x2 encoder
+    # features, x3 seam-window outputs: `p2p_wait` is what the rank still had to wait for after the work it did meanwhile), p2p or
+    # all_gather (x4 composed frames)
+    import time as _time
+
+    def _mark(kind, nbytes=0):
+        if timeline is None:
+            return
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        now = _time.perf_counter()
+        timeline.append((kind, round((now - _mark.t0) * 1e3, 3), int(nbytes)))
+        _mark.t0 = now
+    _mark.t0 = _time.perf_counter()
+
+    def _nbytes(sends):
+        return sum(v.numel() * v.element_size() for v in sends.values())
     try:
         t = next(gen)
         while True:
+            _mark("compute")
             if isinstance(t, tuple) and t[0] == "p2p_start":
                 out = ("done", finish(post(t[1], t[2]))) if blocking else post(t[1], t[2])
             elif isinstance(t, tuple) and t[0] == "p2p_wait":
@@ -454,8 +474,12 @@ def run_distributed(backend, config: ProPainterConfig, frames_u8, flow_masks_u8,
                 outh = [torch.empty_like(th) for _ in range(plan.world)]
                 dist.all_gather(outh, th, group=group)
                 out = [o.to(t.device) for o in outh]
+            if timeline is not None:
+                _mark(t[0] if isinstance(t, tuple) else "all_gather",
+                      _nbytes(t[1]) if isinstance(t, tuple) and isinstance(t[1], dict) else (0 if isinstance(t, tuple) else t.numel() * t.element_size()))
             t = gen.send(out)
     except StopIteration as stop:
+        _mark("compute")
         return stop.value
 
 

@@ -68,12 +68,14 @@ class GraphCache:
             # tensors, allocator growth) must not happen inside the capture
             s = torch.cuda.Stream(inputs[0].device)
             s.wait_stream(torch.cuda.current_stream())
-            ops.PIN_DEVICE_INTS += 1      # index tensors requested from here on are baked into the graph: never evicted
             # one capture at a time per process: torch registers the device's RNG state with a capture and refuses a second
             # concurrent one ("Cannot register the state during capturing stage") -- the rank threads of
             # distributed.run_multi_device capture their sweeps at about the same moment
             _CAPTURE_LOCK.acquire()
             try:
+                # (the counter is only touched under the capture lock -- a lost update between rank threads could
+                #  have un-pinned index tensors whose addresses a graph had baked in)
+                ops.PIN_DEVICE_INTS += 1      # index tensors requested from here on are baked into the graph: never evicted
                 with torch.cuda.stream(s):
                     fn(*static_in)
                 torch.cuda.current_stream().wait_stream(s)
@@ -83,8 +85,8 @@ class GraphCache:
                 with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                     out = fn(*static_in)
             finally:
+                ops.PIN_DEVICE_INTS = max(0, ops.PIN_DEVICE_INTS - 1)
                 _CAPTURE_LOCK.release()
-                ops.PIN_DEVICE_INTS -= 1
             e = _Entry(g, static_in, out)
             self._entries[key] = e
             while len(self._entries) > _MAX_GRAPHS:

@@ -301,7 +301,17 @@ def _shard_devices(config: ProPainterConfig, device: torch.device) -> list:
     if want in ("", "0", "1") or TRACE is not None or device.type != "cuda":
         return [device]
     have = torch.cuda.device_count()
-    n = have if want == "all" else int(want)
+    if want == "all":
+        n = have
+    else:
+        try:
+            n = int(want)
+        except ValueError:
+            n = 0
+        if n < 1:      # (junk / negative values must not raise inside the node call or slice from the end)
+            import warnings
+            warnings.warn(f"PP_GPUS={want!r} is not a positive integer or 'all': running on one device")
+            return [device]
     sv = config.subvideo_length
     nchunks = (config.video_length + sv - 1) // sv
     if sv > 100 or nchunks < 2:

@@ -71,6 +71,7 @@ CONV_PROFILE: ConvProfile | None = None
 
 _INT_CACHE: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()   # bounded LRU: lists no captured graph refers to
 _INT_PINNED: dict = {}                                            # lists handed out while a hipGraph was being captured
+_INT_EVENTS: dict = {}                                            # upload events of lists that may not have landed yet
 _INT_CACHE_MAX = 4096
 _INT_LOCK = threading.Lock()
 PIN_DEVICE_INTS = 0   # > 0 while graphs.GraphCache warms up / captures a sweep (its replays read these addresses)
@@ -85,23 +86,45 @@ def device_ints(values, device, dtype: torch.dtype = torch.int64) -> torch.Tenso
     key = (tuple(values), str(device), dtype)
     with _INT_LOCK:      # (the rank threads of distributed.run_multi_device share the cache)
         t = _INT_PINNED.get(key)
-        if t is not None:
-            return t
-        t = _INT_CACHE.get(key)
         if t is None:
-            t = torch.tensor(list(values), dtype=dtype, device=device)
-            if t.is_cuda and not torch.cuda.is_current_stream_capturing():   # another thread / stream may be the next user: the upload must have landed
-                torch.cuda.current_stream(t.device).synchronize()
+            t = _INT_CACHE.get(key)
+            if t is not None:
+                _INT_CACHE.move_to_end(key)
+        ev = _INT_EVENTS.get(key) if t is not None else None
+    if t is None:
+        # upload OUTSIDE the lock (a host synchronize under the process-wide lock stalled every rank thread behind one
+        # rank's stream): the upload is ordered on the creating thread's stream; any OTHER stream that picks the tensor up later
+        # waits for the event recorded behind it (below) instead of the host waiting for the stream
+        t = torch.tensor(list(values), dtype=dtype, device=device)
+        ev = None
+        if t.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(t.device))
+        with _INT_LOCK:
+            t0 = _INT_PINNED.get(key) or _INT_CACHE.get(key)
+            if t0 is not None:          # another thread was faster: use its tensor (and its event)
+                t, ev = t0, _INT_EVENTS.get(key)
+            else:
+                if ev is not None:
+                    _INT_EVENTS[key] = ev
+                if PIN_DEVICE_INTS > 0:
+                    _INT_PINNED[key] = t
+                else:
+                    _INT_CACHE[key] = t
+                    while len(_INT_CACHE) > _INT_CACHE_MAX:
+                        k0, _ = _INT_CACHE.popitem(last=False)
+                        _INT_EVENTS.pop(k0, None)
+    elif PIN_DEVICE_INTS > 0:
+        with _INT_LOCK:
+            if key in _INT_CACHE:
+                _INT_PINNED[key] = _INT_CACHE.pop(key)
+    if ev is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if ev.query():
+            with _INT_LOCK:
+                _INT_EVENTS.pop(key, None)      # landed: later users need no wait
         else:
-            _INT_CACHE.move_to_end(key)
-        if PIN_DEVICE_INTS > 0:
-            _INT_CACHE.pop(key, None)
-            _INT_PINNED[key] = t
-            return t
-        _INT_CACHE[key] = t
-        while len(_INT_CACHE) > _INT_CACHE_MAX:
-            _INT_CACHE.popitem(last=False)
-        return t
+            torch.cuda.current_stream(t.device).wait_event(ev)   # (a no-op on the stream that uploaded it)
+    return t
 
 
 def dtype_code(dt: torch.dtype) -> int:
@@ -558,11 +581,14 @@ _TILED_INDEX: dict = {}
 def tiled_order_index(h: int, w: int, device) -> torch.Tensor:
     """tiled_order(h, w) as an int64 device tensor, built once per (h, w, device) (RAFT asks for it per chunk: the list is
     ~15k integers at 90x160)."""
-    key = (h, w, str(device))
-    t = _TILED_INDEX.get(key)
-    if t is None:
-        t = _TILED_INDEX[key] = torch.tensor(_tiled_order(h, w), dtype=torch.int64, device=device)
-    return t
+    # (ADVICE r04: same hand-over as device_ints -- cached by value, uploaded outside any lock, a later user on another stream
+    #  waits for the upload's event)
+    return device_ints(_tiled_order_cached(h, w), device)
+
+
+@functools.lru_cache(maxsize=16)
+def _tiled_order_cached(h: int, w: int) -> tuple:
+    return tuple(_tiled_order(h, w))
 
 
 def avgpool2x2(x: torch.Tensor, out: torch.Tensor, hw: tuple[int, int] | None = None, in_tiled: bool = False,

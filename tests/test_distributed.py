@@ -60,7 +60,11 @@ def _worker(rank, world, port, T, nl, rs, sv, out_dir, gather_root=None):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames, fm, md = _toy_inputs(T)
-    res = D.run_distributed(ToyBackend(), _cfg(T, nl, rs, sv), frames, fm, md, gather_root=gather_root)
+    tl = []     # (r05) the per-rank segment clock bench.py --gpus N prints: same results with it, every exchange of the protocol listed
+    res = D.run_distributed(ToyBackend(), _cfg(T, nl, rs, sv), frames, fm, md, gather_root=gather_root, timeline=tl)
+    kinds = [k for k, _, _ in tl]
+    assert kinds[0] == "compute" and kinds[-1] == "compute" and kinds.count("p2p_start") == kinds.count("p2p_wait") == 2
+    assert all(ms >= 0 for _, ms, _ in tl) and any(b > 0 for k, _, b in tl if k != "compute")
     torch.save(res, Path(out_dir) / f"r{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
