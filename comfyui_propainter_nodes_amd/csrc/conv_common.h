@@ -506,7 +506,9 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     if constexpr (sizeof(OT) == 2) return f4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
     else return r;
   };
-  RowLd rl[2];
+  // (LDS form: the loads of row b + 1 are issued before the stores of row b -- two buffers; direct form, on the 128-register GEMM
+  //  tiles with four waves per SIMD to cover a latency: one buffer, a row's loads are issued when the row begins)
+  RowLd rl[LDS ? 2 : 1];
   auto ldq = [&](const OT* base, uint32_t off) PP_INLINE_LAMBDA {
     return *reinterpret_cast<const rawq*>(reinterpret_cast<const char*>(base) + off);
   };
@@ -576,11 +578,12 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     }
   };
   PP_EPI_STAMP(e, 1);
-  issue_row(std::integral_constant<int, 0>{}, rl[0]);
+  if constexpr (LDS) issue_row(std::integral_constant<int, 0>{}, rl[0]);
   PP_EPI_STAMP(e, 2);
   static_for<NB>([&](auto bi) {
     constexpr int b = decltype(bi)::value;
-    RowLd& r = rl[b & 1];
+    RowLd& r = rl[LDS ? (b & 1) : 0];
+    if constexpr (!LDS) issue_row(bi, r);
     f4 v[NA];
     if constexpr (LDS) {
       static_for<NA>([&](auto ai) {
@@ -592,7 +595,7 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     } else {
       static_for<NA>([&](auto ai) { v[decltype(ai)::value] = val(ai, bi); });
     }
-    if constexpr (b + 1 < NB) issue_row(std::integral_constant<int, b + 1>{}, rl[(b + 1) & 1]);  // before this row's stores
+    if constexpr (LDS && b + 1 < NB) issue_row(std::integral_constant<int, b + 1>{}, rl[(b + 1) & 1]);  // before this row's stores
     OT* rowp = e.out + r.m0 * p.out_ldc;
     if (r.nvalid >= 16 && full_c) {        // (uniform) the whole row is stored: no predicate
 #pragma unroll
