@@ -508,7 +508,16 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
   };
   // (LDS form: the loads of row b + 1 are issued before the stores of row b -- two buffers; direct form, on the 128-register GEMM
   //  tiles with four waves per SIMD to cover a latency: one buffer, a row's loads are issued when the row begins)
-  RowLd rl[LDS ? 2 : 1];
+  // (a translation unit whose kernels are short of registers -- conv_split.hip: the flat PP_F32X2 tiles keep two pixel register sets
+  //  in their loop -- defines PP_EPI_ONE_BUFFER_FP32_HEAVY: the fp32 variants with three loaded tensors (GRU blend + pre-add, the
+  //  catch-all) then keep ONE buffer as well; two are 96 registers beside the 64 accumulators and made those kernels spill 116
+  //  registers: tests/test_isa_audit.py)
+#ifdef PP_EPI_ONE_BUFFER_FP32_HEAVY
+  constexpr bool AHEAD = LDS && !(sizeof(OT) == 4 && (RT || EPI == PP_EPI_GRU));
+#else
+  constexpr bool AHEAD = LDS;
+#endif
+  RowLd rl[AHEAD ? 2 : 1];
   auto ldq = [&](const OT* base, uint32_t off) PP_INLINE_LAMBDA {
     return *reinterpret_cast<const rawq*>(reinterpret_cast<const char*>(base) + off);
   };
@@ -578,12 +587,12 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     }
   };
   PP_EPI_STAMP(e, 1);
-  if constexpr (LDS) issue_row(std::integral_constant<int, 0>{}, rl[0]);
+  if constexpr (AHEAD) issue_row(std::integral_constant<int, 0>{}, rl[0]);
   PP_EPI_STAMP(e, 2);
   static_for<NB>([&](auto bi) {
     constexpr int b = decltype(bi)::value;
-    RowLd& r = rl[LDS ? (b & 1) : 0];
-    if constexpr (!LDS) issue_row(bi, r);
+    RowLd& r = rl[AHEAD ? (b & 1) : 0];
+    if constexpr (!AHEAD) issue_row(bi, r);
     f4 v[NA];
     if constexpr (LDS) {
       static_for<NA>([&](auto ai) {
@@ -595,7 +604,7 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     } else {
       static_for<NA>([&](auto ai) { v[decltype(ai)::value] = val(ai, bi); });
     }
-    if constexpr (LDS && b + 1 < NB) issue_row(std::integral_constant<int, b + 1>{}, rl[(b + 1) & 1]);  // before this row's stores
+    if constexpr (AHEAD && b + 1 < NB) issue_row(std::integral_constant<int, b + 1>{}, rl[(b + 1) & 1]);  // before this row's stores
     OT* rowp = e.out + r.m0 * p.out_ldc;
     if (r.nvalid >= 16 && full_c) {        // (uniform) the whole row is stored: no predicate
 #pragma unroll
