@@ -376,11 +376,36 @@ def _conv2d_params(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor
     return P
 
 
+_PARAMS: "OrderedDict[tuple, object]" = OrderedDict()   # filled pp_conv2d_params blocks by launch identity (bounded FIFO)
+_PARAMS_MAX = 16384
+_PARAMS_LOCK = threading.Lock()
+
+
+def _tkey(t):
+    return None if t is None else (t.data_ptr(), t.shape, t.stride(), t.dtype)
+
+
 def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, aux1=None, aux2=None, pre_add=None,
            **kw) -> torch.Tensor:
     """Launch pp_conv2d.  `inputs` are channels-last views (the K segments), `out` a
     channels-last view `[N, Ho, Wo, >=Cout*groups]` that receives the result.  Keywords: _conv2d_params."""
     L = _lib.current()
+    if CONV_PROFILE is None:
+        # r05: the filled parameter block of a launch is kept by (layer, tensor identities, keywords).  A clip repeats the same
+        # launches on the same buffers (the caching allocator hands the same addresses back), so in the steady state a convolution
+        # costs one key and one dictionary lookup on the host instead of ~45 ctypes field stores and the shape checks behind them:
+        # the host side of a clip (bench.py: host_enqueue_ms) matters once N rank threads share the interpreter (PP_GPUS=N).
+        key = (id(spec), spec.weight.data_ptr(), id(L), tuple(map(_tkey, inputs)), _tkey(out), _tkey(aux1), _tkey(aux2),
+               _tkey(pre_add), tuple((k, tuple(v) if isinstance(v, list) else v) for k, v in kw.items()))
+        P = _PARAMS.get(key)
+        if P is None:
+            P = _conv2d_params(spec, inputs, out, aux1=aux1, aux2=aux2, pre_add=pre_add, **kw)
+            with _PARAMS_LOCK:
+                _PARAMS[key] = P
+                while len(_PARAMS) > _PARAMS_MAX:
+                    _PARAMS.popitem(last=False)
+        L.call("pp_conv2d", stream_handle(out), P)
+        return out
     P = _conv2d_params(spec, inputs, out, aux1=aux1, aux2=aux2, pre_add=pre_add, **kw)
     x0 = inputs[0]
     n, h, w, _, _ = nhwc_view(x0)
