@@ -354,6 +354,18 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
 #endif
       // ---- G3
       if (has1) read_al(w1);
+#ifdef PP_HALO_TAILBUF
+      // experiment (tools/build_variant.sh): ah / bh of step q + 1 into a second register set while G3 still multiplies with the
+      // current ones (the kernel has ~45 registers to spare), copied over behind G3 -- no fragment read left in the tail
+      h8 ah_n[TC], bh_n[TP];
+      if (has1) {
+        constexpr int tapoff_n = (NextTap::value / KW) * HW + (NextTap::value % KW);
+#pragma unroll
+        for (int a = 0; a < TC; ++a) ah_n[a] = lds_frag(wfrag_h + w1 * WSTAGE + a * 16 * ROWB);
+#pragma unroll
+        for (int b = 0; b < TP; ++b) bh_n[b] = lds_frag(xfrag + (b * HW + tapoff_n) * XP);
+      }
+#endif
 #pragma unroll
       for (int a = 0; a < TC; ++a)
 #pragma unroll
@@ -363,10 +375,19 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
 #endif
       PP_TR_NOW(tr_b);
       // ---- tail
+#ifdef PP_HALO_TAILBUF
+      if (has1) {
+#pragma unroll
+        for (int a = 0; a < TC; ++a) ah[a] = ah_n[a];
+#pragma unroll
+        for (int b = 0; b < TP; ++b) bh[b] = bh_n[b];
+      }
+#else
       if (has1) {
         read_ah(w1);
         read_bh(NextTap{});
       }
+#endif
       // the weights of step q + 2 must have landed; this step's copies (step q + 3) and, at tap XF, the pixel fetch issued in
       // front of them may stay in flight (the queue retires in order: one tap later the pixels are through as well)
       if (has3) {
