@@ -92,3 +92,26 @@ def test_subvideo_overlap_is_bit_identical_to_the_serial_stages(hip_lib, monkeyp
             assert torch.equal(pipeline.run_inpainting(models, fr, fm, md, cfg), serial)
         monkeypatch.delenv("PP_SUBVIDEO_OVERLAP")
         assert torch.equal(pipeline.run_inpainting(models, fr, fm, md, cfg), serial)      # the default rule
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fp16", ["enable", "disable"])
+def test_epilogue_forms_are_bit_identical_end_to_end(hip_lib, pp_knobs, fp16):
+    """r05: the LDS-transposed lean epilogue variants (conv_common.h: epilogue_lds_variant -- compile-time (act, act2, op, pre-add,
+    out-scale) variants, scale + bias as one fma, -0.0 for a missing bias) against the r01 general form (PP_CONV_EPI=direct), through
+    the WHOLE pipeline in both storage modes: every fused epilogue the networks use (GRU blend, r * h from channel 128 with a
+    pre-activation addend, tanh | relu and tanh x scale | sigmoid splits, residual adds, leaky + add) must give the same frames
+    bit for bit."""
+    from comfyui_propainter_nodes_amd import ops
+
+    dev = torch.device("cuda:0")
+    g = np.load(GOLD / "e2e_chunked.npz")
+    T, H, W, iters, nl, rs, sv, _, _, seed = [int(v) for v in g["params"]]
+    cfg = pipeline.ProPainterConfig(rs, nl, sv, iters, fp16, T, dev, (W, H))
+    pp_knobs(PP_GRAPHS="0")     # (a captured hipGraph would replay the form it was captured with)
+    models = pipeline.models_from_state_dicts(weights.synth_state_dicts(seed), dev, fp16)
+    lean = pipeline.run_inpainting(models, g["frames_u8"], g["flow_masks"], g["masks_dilated"], cfg)
+    pp_knobs(PP_CONV_EPI="direct")
+    ops._PARAMS.clear()
+    direct = pipeline.run_inpainting(models, g["frames_u8"], g["flow_masks"], g["masks_dilated"], cfg)
+    assert torch.equal(lean, direct)

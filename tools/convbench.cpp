@@ -41,6 +41,8 @@ static const std::vector<Shape> SHAPES = {
     {"raft_gru128_5x1_f32x2", PP_F32X2, 158, 45, 80, {128, 128}, 128, 5, 1, 2, 0},
     {"raft_gru_1x5_f32", PP_F32, 158, 45, 80, {128, 128}, 256, 1, 5, 0, 2},
     {"raft_convc2_f32x2", PP_F32X2, 158, 45, 80, {256}, 192, 3, 3, 1, 1},
+    {"raft_convc1_f32x2", PP_F32X2, 158, 45, 80, {324}, 256, 1, 1, 0, 0},     // the correlation features' 1x1 projection (flat tiles)
+    {"raft_convf1_f32x2", PP_F32X2, 158, 45, 80, {98}, 128, 1, 1, 0, 0},      // the 7x7 flow stem behind pp_im2col (flat tiles)
     {"raft_fh1_f32x2", PP_F32X2, 158, 45, 80, {128}, 256, 3, 3, 1, 1},
     {"raft_fh2_f32x2", PP_F32X2, 158, 45, 80, {256}, 2, 3, 3, 1, 1},
     {"dec6_f16", PP_F16, 14, 360, 640, {64}, 3, 3, 3, 1, 1},
