@@ -386,3 +386,8 @@ def test_bench_spawns_its_own_ranks(hip_lib):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["frames_per_gpu"] == 40 and line["value"] > 0
+    # r05: the line carries every rank's segment clock of one instrumented step (compute / exchange / wait, bytes sent)
+    ranks = line["per_rank"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["compute_total_ms"] > 0 and r["exchanges"] for r in ranks)
+    assert any(e["kind"] == "p2p_wait" for e in ranks[0]["exchanges"]) and any(e["MB_sent"] > 0 for e in ranks[1]["exchanges"])
+    assert line["host_enqueue_ms"] > 0
