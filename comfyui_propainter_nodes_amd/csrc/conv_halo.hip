@@ -147,11 +147,12 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   // K iterators
   int w_rem = 0, w_seg = 0, w_sbase = 0, w_chunks = p.seg_chunks[0];
   const int tapstride = p.chunks_per_tap * 32;
+  const uint32_t wring_off = lds_offset_of(smem) + (uint32_t)XBYTES + (uint32_t)(wave * 64 * 16);   // this wave's slot of ring stage 0
   auto fetch_w = [&](int wbuf, int tap) PP_INLINE_LAMBDA {  // weights of (the iterator's chunk, tap) -> ring stage wbuf
-    unsigned char* wt = smem + XBYTES + wbuf * WSTAGE;
+    const uint32_t wt = wring_off + (uint32_t)(wbuf * WSTAGE);
     const char* src = reinterpret_cast<const char*>(wptr + (tap * tapstride + w_sbase + w_rem * 32));
 #pragma unroll
-    for (int i = 0; i < WPASS; ++i) glds16_s(src, wlane[i], wt + (i * NT + wave * 64) * 16);
+    for (int i = 0; i < WPASS; ++i) glds16_s(src, wlane[i], wt + (uint32_t)(i * NT * 16));
   };
   auto w_next_chunk = [&]() PP_INLINE_LAMBDA {
     if (++w_rem == w_chunks) {

@@ -78,11 +78,15 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // form): no 64-bit per-lane address -- hipcc builds one with a v_lshl_add_u64 per copy from the builtin above, and next to a
 // matrix-bound partner wave a vector-ALU instruction costs about one MFMA slot (r05).  lds_wave_base must be wave-uniform.
 // Not visible to the compiler's vmcnt accounting: for kernels that count their waits by hand (conv_halo.hip).
-__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, void* lds_wave_base) {
-  const uint32_t m0v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_wave_off) {
+  // lds_wave_off: the wave's destination as an LDS BYTE OFFSET (lds_offset_of() once per kernel + integer arithmetic): a pointer
+  // here would cost a generic -> LDS cast with its null check (two scalar instructions per copy)
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase),
-               "s"(__builtin_amdgcn_readfirstlane(m0v))
+               "s"(__builtin_amdgcn_readfirstlane(lds_wave_off))
                : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t lds_offset_of(const void* lds_ptr) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_ptr;
 }
 __device__ __attribute__((aligned(16))) const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
 // counted wait on the vector-memory queue (global_load_lds copies are tracked by vmcnt) and a bare barrier that
@@ -143,8 +147,11 @@ inline void glds16(const void* g, void* lds_wave_base) {
   memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * pp_emu::cur->lane, g, 16);
 }
 static const unsigned int pp_zero16[4] = {0u, 0u, 0u, 0u};
-inline void glds16_s(const void* sbase, uint32_t voff, void* lds_wave_base) {
-  memcpy(static_cast<unsigned char*>(lds_wave_base) + 16 * pp_emu::cur->lane, static_cast<const char*>(sbase) + voff, 16);
+inline uint32_t lds_offset_of(const void* lds_ptr) {   // (emulator: offsets are relative to the block's dynamic LDS)
+  return (uint32_t)(static_cast<const unsigned char*>(lds_ptr) - pp_emu::dyn_smem);
+}
+inline void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_wave_off) {
+  memcpy(pp_emu::dyn_smem + lds_wave_off + 16 * pp_emu::cur->lane, static_cast<const char*>(sbase) + voff, 16);
 }
 template <int N>
 inline void pp_wait_vmcnt() {}
