@@ -158,7 +158,10 @@ def evaluate_node_case(case, fp16, check=False, timer=None):
     if variant == "contractive":                     # a contractive recurrence: tight at ANY length, inside the hole too
         # measured on the MI355X: fp32 storage 1.56e-2 max / 1.9e-3 mean -- that IS the fixture's f16 storage of flows of up to
         # 36 px (half an ulp = 1.8e-2) --, f16 storage 4.7e-2 / 2.2e-3
-        assert (e_pf < 2.5e-2 and m_pf < 3e-3) if fp16 == "disable" else (e_pf < 0.15 and m_pf < 5e-3)
+        # (the fixture stores the flows as f16: half an ulp of its largest flow bounds what "equal" can mean -- 1.6e-2 at the 36 px
+        #  of the 640x360 clip, 3.1e-2 from 64 px on at 1280x720)
+        half_ulp = float(np.abs(g["pred_flow"].astype(np.float32)).max()) * 2.0 ** -11
+        assert (e_pf < max(2.5e-2, 1.3 * half_ulp) and m_pf < 3e-3) if fp16 == "disable" else (e_pf < max(0.15, 4 * half_ulp) and m_pf < 5e-3)
     elif T > 40:                                     # chaotic inside the hole (see the module docstring)
         assert m_pf < 0.25 and e_pf < 10.0
     elif fp16 == "disable":
