@@ -436,9 +436,7 @@ __device__ __forceinline__ f4 act4_ct(f4 v, int act_rt, float param) {
 //   * whole rows (all 16 pixels inside the image, all channels below Cout) take a path without any per-lane predicate.
 // No wait for a load ever has an older store in front of it: bias quads are loaded once before the first store, the loads of quad
 // row b + 1 are issued BEFORE the stores of row b, and a variant without aux / pre tensors has no load in its loop.
-// LDS = false: the same epilogue on the quads as the MFMA leaves them (a lane keeps its pixel column, its NA quads are 16 channels
-// apart): no staging, used where the LDS round trips cost more than they save (short-reduction GEMMs).
-template <typename OT, int NA, int NB, bool SCALED, bool LDS, int ACT, int ACT2, int EPI, int PRE, int OSC, typename Row0Fn, typename ValFn>
+template <typename OT, int NA, int NB, bool SCALED, int ACT, int ACT2, int EPI, int PRE, int OSC, typename Row0Fn, typename ValFn>
 __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
                                                      Row0Fn row0, ValFn val) {
   constexpr int PITCH = epi_lds_pitch<NA>();
@@ -455,45 +453,23 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
   bool cok[NA], second[NA], from[NA];
   uint32_t o_out[NA], o_a1[NA], o_a2[NA], o_pre[NA], lrd[NA];
   f4 bq[NA];
-  if constexpr (LDS) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int q = i * 64 + lane;
-      px[i] = q / QPR;
-      const int c = c_wave + (q - px[i] * QPR) * 4;
-      cok[i] = c < p.Cout;
-      cc[i] = c < cmax ? c : cmax;
-      second[i] = ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split;
-      from[i] = cc[i] >= p.epi_from;
-      const int ce = from[i] ? cc[i] - p.epi_from : 0;
-      o_out[i] = (uint32_t)(px[i] * p.out_ldc + cc[i]) * (uint32_t)sizeof(OT);
-      o_a1[i] = (uint32_t)(px[i] * p.aux1_ldc + ce) * (uint32_t)sizeof(OT);
-      o_a2[i] = (uint32_t)(px[i] * p.aux2_ldc + ce) * (uint32_t)sizeof(OT);
-      o_pre[i] = (uint32_t)(px[i] * p.pre_add_ldc + cc[i]) * (uint32_t)sizeof(OT);
-      lrd[i] = (uint32_t)(px[i] * PITCH + (q - px[i] * QPR) * 16);
-      bq[i] = f4{-0.f, -0.f, -0.f, -0.f};    // (x * sc + -0.0 == x * sc bit for bit)
-      if (e.bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
-    }
-  } else {
-    // direct quads (the caller guarantees a whole channel tile: c_wave + NA * 16 <= Cout): a lane keeps its pixel column, its
-    // quads are 16 channels apart -- ONE offset register per tensor, the rest are instruction immediates
-    const int c0 = c_wave + fgrp * 4;
-    const int ce0 = c0 >= p.epi_from ? c0 - p.epi_from : 0;   // (epi_from is a multiple of 4; a quad never straddles it)
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      px[i] = frow;
-      cc[i] = c0 + i * 16;
-      cok[i] = true;
-      second[i] = ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split;
-      from[i] = cc[i] >= p.epi_from;
-      o_out[i] = (uint32_t)(frow * p.out_ldc + c0) * (uint32_t)sizeof(OT) + (uint32_t)(i * 16 * sizeof(OT));
-      o_a1[i] = (uint32_t)(frow * p.aux1_ldc + ce0) * (uint32_t)sizeof(OT) + (uint32_t)(from[i] ? (cc[i] - p.epi_from - ce0) * (int)sizeof(OT) : 0);
-      o_a2[i] = (uint32_t)(frow * p.aux2_ldc + ce0) * (uint32_t)sizeof(OT) + (uint32_t)(from[i] ? (cc[i] - p.epi_from - ce0) * (int)sizeof(OT) : 0);
-      o_pre[i] = (uint32_t)(frow * p.pre_add_ldc + c0) * (uint32_t)sizeof(OT) + (uint32_t)(i * 16 * sizeof(OT));
-      lrd[i] = 0u;
-      bq[i] = f4{-0.f, -0.f, -0.f, -0.f};
-      if (e.bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
-    }
+  for (int i = 0; i < NA; ++i) {
+    const int q = i * 64 + lane;
+    px[i] = q / QPR;
+    const int c = c_wave + (q - px[i] * QPR) * 4;
+    cok[i] = c < p.Cout;
+    cc[i] = c < cmax ? c : cmax;
+    second[i] = ACT2 != -2 && p.act_split > 0 && cc[i] >= p.act_split;
+    from[i] = cc[i] >= p.epi_from;
+    const int ce = from[i] ? cc[i] - p.epi_from : 0;
+    o_out[i] = (uint32_t)(px[i] * p.out_ldc + cc[i]) * (uint32_t)sizeof(OT);
+    o_a1[i] = (uint32_t)(px[i] * p.aux1_ldc + ce) * (uint32_t)sizeof(OT);
+    o_a2[i] = (uint32_t)(px[i] * p.aux2_ldc + ce) * (uint32_t)sizeof(OT);
+    o_pre[i] = (uint32_t)(px[i] * p.pre_add_ldc + cc[i]) * (uint32_t)sizeof(OT);
+    lrd[i] = (uint32_t)(px[i] * PITCH + (q - px[i] * QPR) * 16);
+    bq[i] = f4{-0.f, -0.f, -0.f, -0.f};    // (x * sc + -0.0 == x * sc bit for bit)
+    if (e.bias) bq[i] = *reinterpret_cast<const f4*>(e.bias + cc[i]);
   }
   const bool full_c = c_wave + NA * 16 <= p.Cout;   // (uniform) every channel quad of the wave tile exists
   typedef typename std::conditional<sizeof(OT) == 2, h4, f4>::type rawq;   // a loaded quad as it travels: converted at its use
@@ -506,16 +482,15 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     if constexpr (sizeof(OT) == 2) return f4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
     else return r;
   };
-  // (LDS form: the loads of row b + 1 are issued before the stores of row b -- two buffers; direct form, on the 128-register GEMM
-  //  tiles with four waves per SIMD to cover a latency: one buffer, a row's loads are issued when the row begins)
+  // (the loads of row b + 1 are issued before the stores of row b: two buffers)
   // (a translation unit whose kernels are short of registers -- conv_split.hip: the flat PP_F32X2 tiles keep two pixel register sets
   //  in their loop -- defines PP_EPI_ONE_BUFFER_FP32_HEAVY: the fp32 variants with three loaded tensors (GRU blend + pre-add, the
   //  catch-all) then keep ONE buffer as well; two are 96 registers beside the 64 accumulators and made those kernels spill 116
   //  registers: tests/test_isa_audit.py)
 #ifdef PP_EPI_ONE_BUFFER_FP32_HEAVY
-  constexpr bool AHEAD = LDS && !(sizeof(OT) == 4 && (RT || EPI == PP_EPI_GRU));
+  constexpr bool AHEAD = !(sizeof(OT) == 4 && (RT || EPI == PP_EPI_GRU));
 #else
-  constexpr bool AHEAD = LDS;
+  constexpr bool AHEAD = true;
 #endif
   RowLd rl[AHEAD ? 2 : 1];
   auto ldq = [&](const OT* base, uint32_t off) PP_INLINE_LAMBDA {
@@ -594,16 +569,12 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     RowLd& r = rl[AHEAD ? (b & 1) : 0];
     if constexpr (!AHEAD) issue_row(bi, r);
     f4 v[NA];
-    if constexpr (LDS) {
-      static_for<NA>([&](auto ai) {
-        *reinterpret_cast<f4*>(wlds + frow * PITCH + (decltype(ai)::value * 16 + fgrp * 4) * 4) = val(ai, bi);
-      });
-      pp_wave_lds_fence();
+    static_for<NA>([&](auto ai) {
+      *reinterpret_cast<f4*>(wlds + frow * PITCH + (decltype(ai)::value * 16 + fgrp * 4) * 4) = val(ai, bi);
+    });
+    pp_wave_lds_fence();
 #pragma unroll
-      for (int i = 0; i < NA; ++i) v[i] = *reinterpret_cast<const f4*>(wlds + lrd[i]);
-    } else {
-      static_for<NA>([&](auto ai) { v[decltype(ai)::value] = val(ai, bi); });
-    }
+    for (int i = 0; i < NA; ++i) v[i] = *reinterpret_cast<const f4*>(wlds + lrd[i]);
     if constexpr (AHEAD && b + 1 < NB) issue_row(std::integral_constant<int, b + 1>{}, rl[(b + 1) & 1]);  // before this row's stores
     OT* rowp = e.out + r.m0 * p.out_ldc;
     if (r.nvalid >= 16 && full_c) {        // (uniform) the whole row is stored: no predicate
@@ -616,41 +587,37 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
         if (cok[i] && px[i] < r.nvalid) put(rowp, o_out[i], x);
       }
     }
-    if constexpr (LDS) pp_wave_lds_fence();  // the next row's staging writes come after this row's reads
+    pp_wave_lds_fence();  // the next row's staging writes come after this row's reads
     if constexpr (b < 4) { PP_EPI_STAMP(e, 3 + b); }
   });
 }
 
 // Dispatch to the variant of the launch's (act, act2, epi, pre_add, out_scale): the combinations the pipeline's layers use are
 // compiled in, anything else takes the run-time variant (same arithmetic).
-template <typename OT, int NA, int NB, bool SCALED, bool LDS, typename Row0Fn, typename ValFn>
-__device__ __forceinline__ bool epilogue_quads_lds(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
+template <typename OT, int NA, int NB, bool SCALED, typename Row0Fn, typename ValFn>
+__device__ __forceinline__ void epilogue_quads_lds(const ConvK& p, const EpiCtx<OT>& e, unsigned char* wlds, int lane, int c_wave,
                                                    Row0Fn row0, ValFn val) {
   const int a2 = p.act_split > 0 ? p.act2 : -2;
   const int pre = e.pre != nullptr ? 1 : 0;
   const int osc = p.out_scale != 0.f ? 1 : 0;
 #define PP_EPI_VARIANT(A, A2, E, P, O)                                                                       \
   if (p.act == (A) && a2 == (A2) && p.epi == (E) && pre == (P) && osc == (O)) {                             \
-    epilogue_lds_variant<OT, NA, NB, SCALED, LDS, (A), (A2), (E), (P), (O)>(p, e, wlds, lane, c_wave, row0, val);    \
-    return true;                                                                                             \
+    epilogue_lds_variant<OT, NA, NB, SCALED, (A), (A2), (E), (P), (O)>(p, e, wlds, lane, c_wave, row0, val);        \
+    return;                                                                                                  \
   }
   PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 0)
   PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_NONE, 0, 0)
   PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_NONE, 0, 0)
   PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_ADD_AUX1, 0, 0)
-  if constexpr (LDS) {   // (the direct form serves the 128-register GEMM tiles: only variants whose buffers fit beside 64 accumulators)
-    PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_ADD_AUX1_RELU, 0, 0)
-    PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_ADD_AUX1, 0, 0)
-    PP_EPI_VARIANT(PP_ACT_SIGMOID, -2, PP_EPI_MUL_AUX1, 1, 0)
-    PP_EPI_VARIANT(PP_ACT_TANH, -2, PP_EPI_GRU, 1, 0)
-    PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_RELU, PP_EPI_NONE, 0, 0)
-    PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_SIGMOID, PP_EPI_NONE, 0, 1)
-    PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 1)
-    epilogue_lds_variant<OT, NA, NB, SCALED, LDS, -1, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
-    return true;
-  }
+  PP_EPI_VARIANT(PP_ACT_RELU, -2, PP_EPI_ADD_AUX1_RELU, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_LEAKY, -2, PP_EPI_ADD_AUX1, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_SIGMOID, -2, PP_EPI_MUL_AUX1, 1, 0)
+  PP_EPI_VARIANT(PP_ACT_TANH, -2, PP_EPI_GRU, 1, 0)
+  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_RELU, PP_EPI_NONE, 0, 0)
+  PP_EPI_VARIANT(PP_ACT_TANH, PP_ACT_SIGMOID, PP_EPI_NONE, 0, 1)
+  PP_EPI_VARIANT(PP_ACT_NONE, -2, PP_EPI_NONE, 0, 1)
 #undef PP_EPI_VARIANT
-  return false;
+  epilogue_lds_variant<OT, NA, NB, SCALED, -1, -1, -1, -1, -1>(p, e, wlds, lane, c_wave, row0, val);
 }
 
 // One epilogue entry for every convolution kernel: the general form when the launch's views are not vector-aligned, the
@@ -676,18 +643,13 @@ __device__ __forceinline__ void epilogue_any(const ConvK& p, const EpiCtx<OT>& e
       pp_barrier();
     }
     PP_EPI_STAMP(e, 0);
-    epilogue_quads_lds<OT, NA, NB, SCALED, true>(p, e, smem + wave * epi_lds_wave_bytes<NA>(), lane, c_wave, row0, val);
+    epilogue_quads_lds<OT, NA, NB, SCALED>(p, e, smem + wave * epi_lds_wave_bytes<NA>(), lane, c_wave, row0, val);
   } else {
-    // The GEMM / flat implicit-GEMM tiles live on <= 128 registers per wave (two 8-wave work-groups per CU).  r05 measured the lean
-    // variants on them twice: with the catch-all variant compiled in (fc1 611 -> 460 TF/s: 138-154 registers, one work-group per
-    // CU), and restricted to the four variants these layers use with one offset register per tensor (still 138; forced to 128 the
-    // compiler spills 36 / 96 registers).  These kernels keep the r04 fast form; PP_CONV_EPI_DIRECT_LEAN (compile time) re-enables
-    // the experiment.
-#ifdef PP_CONV_EPI_DIRECT_LEAN
-    if (epi_fast_ok<OT>(p, e) && p.epi_lds && c_wave + NA * 16 <= p.Cout && p.epi_from == 0) {   // (whole channel tiles only)
-      if (epilogue_quads_lds<OT, NA, NB, SCALED, false>(p, e, nullptr, lane, c_wave, row0, val)) return;
-    }
-#endif
+    // The GEMM / flat implicit-GEMM tiles live on <= 128 registers per wave (two 8-wave work-groups per CU) and keep the r04 fast
+    // form.  r05 measured the lean variants on them three times (LDS-transposed; on the direct quads with the catch-all variant;
+    // on the direct quads with four variants and one row buffer at 128 registers, 8 spills): fc1 611 -> 460 / 460 / 642, qkv 588 ->
+    // 464 / 464 / 566 TF/s -- their epilogue is not what they wait for.  (tools/experiments/r05_halo_hooks.patch holds the
+    // direct-quad form.)
     epilogue_quads<OT, NA, NB>(p, e, row, chan, val_s);
   }
 }

@@ -30,11 +30,7 @@ namespace pp {
 // so its source is either 8 consecutive channels of one input pixel or, outside the image, zeros.  Same chunks in the same
 // order as the GEMM over the materialised patch matrix: bit-identical to unfold + GEMM.
 template <typename OT, int WC, int WP, int TC, int TP, int KC, int NST, bool PATCH = false>
-#ifdef PP_CONV_EPI_DIRECT_LEAN
-__global__ void __launch_bounds__(WC * WP * 64, (WC * WP == 8 ? 4 : 1)) conv_gemm_f16_kernel(const ConvK p) {   // 8-wave tiles: <= 128 registers
-#else
 __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK p) {
-#endif
   typedef half_t T;
   constexpr int NT = WC * WP * 64;
   constexpr int BC = WC * TC * 16, BP = WP * TP * 16;

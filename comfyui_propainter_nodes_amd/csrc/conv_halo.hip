@@ -44,16 +44,9 @@ namespace pp {
 //  * the pipeline decisions (which tap fetches the next pixel tile, which one stores it, the counted waits) are resolved at
 //    compile time.
 //
-// Experiment hook for the next occupancy A/B (r04 counters: matrix pipe 53-61 % busy, 2 waves per SIMD, the cover comes from
-// INDEPENDENT work-groups): -DPP_HALO_TRIM64 (tools/build_variant.sh) sends every layer to the 64-channel x (8 x 16) tile (152
-// registers) and trims the pixel tile to its HROWS rows, so that THREE work-groups fit a CU (3 x <= 53.4 KB) instead of two.  Not
-// defined in the product build: the constant folds away (the product's code objects are unchanged, tools/shipped_isa.py).
-#ifdef PP_HALO_TRIM64
-constexpr bool kHaloTrim64 = true;
-#else
-constexpr bool kHaloTrim64 = false;
-#endif
-
+// (r05: the 64-channel-tile / three-work-groups-per-CU build of these kernels -- -DPP_HALO_TRIM64, prepared in r04 -- was measured:
+//  GRU 1x5 329.8 -> 317.3 TF/s, 5x1 128-channel 290 -> 255, 3x3 unchanged; and the last fragment reads of a step into a second
+//  register set -- -DPP_HALO_TAILBUF --: identical times.  Both hooks are archived in tools/experiments/r05_halo_hooks.patch.)
 // Phase trace (tools/trace_halo.sh, -DPP_HALO_TRACE; not defined in the product build): every wave accumulates, in scalar
 // registers, the s_memtime ticks it spends per tap in (issue = weight / pixel copies issued) (compute = fragment reads + MFMAs)
 // (close = counted waits + barrier [+ split / store of the next pixel tile at the last tap of a chunk]) and writes the sums behind
@@ -68,7 +61,7 @@ constexpr bool kHaloTrim64 = false;
 #endif
 
 template <int WC, int WP, int TC, int TP, int KH, int KW>
-__global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)) conv_halo_split_ct_kernel(const ConvK p, const HaloGeom g) {
+__global__ void __launch_bounds__(WC * WP * 64, 2) conv_halo_split_ct_kernel(const ConvK p, const HaloGeom g) {
   typedef float OT;
   constexpr int NT = WC * WP * 64;
   constexpr int TH = WP * TP;
@@ -81,7 +74,7 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   constexpr int HROWS = (TH + KH - 1) * HW;
   constexpr int XPASS = (HROWS + XROWS - 1) / XROWS;
   constexpr int WPASS = BCP / WROWS;
-  constexpr int XBYTES = (kHaloTrim64 ? HROWS : XPASS * XROWS) * XP, WSTAGE = BCP * ROWB;
+  constexpr int XBYTES = XPASS * XROWS * XP, WSTAGE = BCP * ROWB;
   constexpr int NX = 2 * XPASS;
   constexpr int NTAPS = KH * KW;
   static_assert(TH == 8 && NTAPS >= 2 && HROWS <= kHaloMaxRows, "geometry");
@@ -222,7 +215,6 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
   auto store_x = [&]() PP_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < XPASS; ++i) {
-      if (kHaloTrim64 && xrow0 + i * XROWS >= HROWS) continue;   // trimmed tile: the rows past the halo tile do not exist
       if (wave * 16 + i * XROWS >= HROWS) continue;             // (scalar) this wave's rows of the pass are never read
 #ifdef PP_EMU
       const bool all_ok = false;
@@ -355,18 +347,6 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
 #endif
       // ---- G3
       if (has1) read_al(w1);
-#ifdef PP_HALO_TAILBUF
-      // experiment (tools/build_variant.sh): ah / bh of step q + 1 into a second register set while G3 still multiplies with the
-      // current ones (the kernel has ~45 registers to spare), copied over behind G3 -- no fragment read left in the tail
-      h8 ah_n[TC], bh_n[TP];
-      if (has1) {
-        constexpr int tapoff_n = (NextTap::value / KW) * HW + (NextTap::value % KW);
-#pragma unroll
-        for (int a = 0; a < TC; ++a) ah_n[a] = lds_frag(wfrag_h + w1 * WSTAGE + a * 16 * ROWB);
-#pragma unroll
-        for (int b = 0; b < TP; ++b) bh_n[b] = lds_frag(xfrag + (b * HW + tapoff_n) * XP);
-      }
-#endif
 #pragma unroll
       for (int a = 0; a < TC; ++a)
 #pragma unroll
@@ -376,19 +356,10 @@ __global__ void __launch_bounds__(WC * WP * 64, (kHaloTrim64 && WC == 1 ? 3 : 2)
 #endif
       PP_TR_NOW(tr_b);
       // ---- tail
-#ifdef PP_HALO_TAILBUF
-      if (has1) {
-#pragma unroll
-        for (int a = 0; a < TC; ++a) ah[a] = ah_n[a];
-#pragma unroll
-        for (int b = 0; b < TP; ++b) bh[b] = bh_n[b];
-      }
-#else
       if (has1) {
         read_ah(w1);
         read_bh(NextTap{});
       }
-#endif
       // the weights of step q + 2 must have landed; this step's copies (step q + 3) and, at tap XF, the pixel fetch issued in
       // front of them may stay in flight (the queue retires in order: one tap later the pixels are through as well)
       if (has3) {
@@ -460,7 +431,7 @@ static int launch_halo_ct_cfg(void* stream, const ConvK& k, int Z, HaloGeom g) {
   constexpr int BCP = (BC + NT / 8 - 1) / (NT / 8) * (NT / 8);
   constexpr int HROWS = (8 + KH - 1) * (kHaloTW + KW - 1);
   constexpr int XPASS = (HROWS + NT / 4 - 1) / (NT / 4);
-  const size_t smem = (size_t)(kHaloTrim64 ? HROWS : XPASS * (NT / 4)) * 160 + (size_t)3 * BCP * 128;
+  const size_t smem = (size_t)XPASS * (NT / 4) * 160 + (size_t)3 * BCP * 128;
   g.nct = (k.Cout + BC - 1) / BC;
   dim3 grid((unsigned)(g.ntiles * g.nct), 1u, (unsigned)Z);
 #ifdef PP_HALO_TRACE
@@ -523,7 +494,7 @@ int launch_halo_split(void* stream, const ConvK& k, int Z) {
   // (A two-group form -- one 8-wave work-group per CU, two pixel tiles sharing the weight ring, group 1 held half a step
   // behind group 0 by an extra barrier so that one group's MFMA burst always met the other's loads -- was built, checked
   // on the MI355X and measured SLOWER: RAFT GRU 1x5 228 vs 277 TF/s, 3x3 256->192 254 vs 320; removed)
-  if (k.Cout > 64 && !kHaloTrim64) {
+  if (k.Cout > 64) {
     const int waste128 = (k.Cout + 127) / 128 * 128 - k.Cout;
     const int waste96 = (k.Cout + 95) / 96 * 96 - k.Cout;
     if (waste96 + 32 <= waste128) return launch_halo_any<2, 2, 3, 4>(stream, k, Z, g);  //  96 x (8 x 16)
