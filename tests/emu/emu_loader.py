@@ -10,7 +10,7 @@ from comfyui_propainter_nodes_amd import build as B
 from comfyui_propainter_nodes_amd import lib
 
 EMU_DIR = Path(__file__).resolve().parent
-# PP_EMU_DEFINES="-DPP_HALO_TRACE": the emulation of an experiment build (csrc hooks compiled in by tools/build_variant.sh for
+# PP_EMU_DEFINES="-D<hook>": the emulation of an experiment build (csrc hooks compiled in by tools/build_variant.sh for
 # the GPU) in its own object directory and library, so that a kernel variant is checked on CPU before it is timed on the MI355X
 VARIANT_DEFINES = os.environ.get("PP_EMU_DEFINES", "").split()
 _TAG = "".join(c if c.isalnum() else "_" for c in "_".join(VARIANT_DEFINES))
