@@ -483,15 +483,9 @@ __device__ __forceinline__ void epilogue_lds_variant(const ConvK& p, const EpiCt
     else return r;
   };
   // (the loads of row b + 1 are issued before the stores of row b: two buffers)
-  // (a translation unit whose kernels are short of registers -- conv_split.hip: the flat PP_F32X2 tiles keep two pixel register sets
-  //  in their loop -- defines PP_EPI_ONE_BUFFER_FP32_HEAVY: the fp32 variants with three loaded tensors (GRU blend + pre-add, the
-  //  catch-all) then keep ONE buffer as well; two are 96 registers beside the 64 accumulators and made those kernels spill 116
-  //  registers: tests/test_isa_audit.py)
-#ifdef PP_EPI_ONE_BUFFER_FP32_HEAVY
+  // (the fp32 variants with three loaded tensors -- GRU blend + pre-add, the catch-all -- keep ONE buffer: two are 96 registers beside
+  //  the 64 accumulators, which made the 256-register kernels spill 56-116 registers: tests/test_isa_audit.py, tools/shipped_isa.py)
   constexpr bool AHEAD = !(sizeof(OT) == 4 && (RT || EPI == PP_EPI_GRU));
-#else
-  constexpr bool AHEAD = true;
-#endif
   RowLd rl[AHEAD ? 2 : 1];
   auto ldq = [&](const OT* base, uint32_t off) PP_INLINE_LAMBDA {
     return *reinterpret_cast<const rawq*>(reinterpret_cast<const char*>(base) + off);

@@ -18,7 +18,6 @@
 //
 // Arithmetic, weight packing, K order and epilogue are those of conv_split_kernel (same results up to fp32 summation
 // order -- identical order in fact: chunk by chunk, tap by tap).  The f16 form lives in conv_halo_f16.hip.
-#define PP_EPI_ONE_BUFFER_FP32_HEAVY 1   // (conv_common.h: epilogue_lds_variant -- 256-register kernels: two row buffers of three fp32 tensors spill)
 #include "conv_halo_common.h"
 #ifdef PP_HALO_TRACE
 #include <vector>

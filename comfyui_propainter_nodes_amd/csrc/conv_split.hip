@@ -1,6 +1,5 @@
 // conv_split.hip -- pp_conv2d in PP_F32X2 mode: f32 convolution on the f16 matrix pipe (see conv_igemm.hip for the
 // implicit-GEMM formulation and include/propainter_mi355.h for the weight layout).
-#define PP_EPI_ONE_BUFFER_FP32_HEAVY 1   // (conv_common.h: epilogue_lds_variant -- these kernels are short of registers)
 #include "conv_common.h"
 
 namespace pp {
