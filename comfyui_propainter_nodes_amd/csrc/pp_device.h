@@ -131,12 +131,15 @@ __device__ __forceinline__ void pp_barrier() {
   asm volatile("" ::: "memory");
 }
 // Lanes of ONE wave hand data to each other through a wave-private LDS region: the wave executes its LDS instructions in
-// program order, so no s_barrier is needed -- only the compiler must not move a lane's reads above the other lanes' writes
-// (per thread the addresses differ, so without the fence it may) and the writes must have left the wave (lgkmcnt).
+// program order, so no s_barrier is needed -- but the COMPILER must not move a lane's reads above the other lanes' writes: per
+// thread the two addresses differ, so nothing in the C++ memory model orders them.  r05 first used wavefront-scope fences +
+// __builtin_amdgcn_wave_barrier() here; LLVM lowers those to nothing and keeps its freedom: one build of the flat PP_F32X2 kernel
+// read its staging rows before writing them (stale weight bytes as floats: 4e32 in tests/test_conv.py on the MI355X; every earlier
+// build had happened to keep the order).  An asm statement with a memory clobber is a barrier the optimiser cannot see through;
+// the lgkmcnt(0) in it retires the writes before the reads are issued.
 __device__ __forceinline__ void pp_wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
