@@ -260,6 +260,7 @@ class ConvSpec:
     split: bool = False           # f32 tensors on the f16 matrix pipe (PP_F32X2 weight packing)
     acc_scale: float = 0.0        # PP_F32X2: 1 / (the power-of-two scale inside the packed weights); 0 = 1
     weight_f32: torch.Tensor | None = None  # Cout <= 4 only: fp32 [tap*chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
+    geometry_key: tuple | None = None       # (conv2d's parameter-block cache: the fields above that a block depends on, built once)
 
     def to(self, device) -> "ConvSpec":
         self.weight = self.weight.to(device)
@@ -402,8 +403,16 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, aux
         # launches on the same buffers (the caching allocator hands the same addresses back), so in the steady state a convolution
         # costs one key and one dictionary lookup on the host instead of ~45 ctypes field stores and the shape checks behind them:
         # the host side of a clip (bench.py: host_enqueue_ms) matters once N rank threads share the interpreter (PP_GPUS=N).
-        key = (id(spec), spec.weight.data_ptr(), id(L), tuple(map(_tkey, inputs)), _tkey(out), _tkey(aux1), _tkey(aux2),
-               _tkey(pre_add), tuple((k, tuple(v) if isinstance(v, list) else v) for k, v in kw.items()))
+        # (the key names everything _conv2d_params reads: the layer's geometry and ITS buffers -- not the spec object's id: a test that
+        #  builds one layer after another gets the same id, the same weight address and the same tensor addresses back for a
+        #  different geometry; tests/test_conv.py caught exactly that on the MI355X)
+        geo = spec.geometry_key
+        if geo is None:
+            geo = spec.geometry_key = (spec.cout, spec.kh, spec.kw, spec.sh, spec.sw, spec.ph, spec.pw, spec.dh, spec.dw, spec.groups,
+                                       spec.pad_mode, tuple(spec.seg_channels), spec.split, spec.acc_scale, tuple(spec.weight.shape))
+        key = (geo, spec.weight.data_ptr(), None if spec.bias is None else spec.bias.data_ptr(),
+               None if spec.weight_f32 is None else spec.weight_f32.data_ptr(), id(L), tuple(map(_tkey, inputs)), _tkey(out),
+               _tkey(aux1), _tkey(aux2), _tkey(pre_add), tuple((k, tuple(v) if isinstance(v, list) else v) for k, v in kw.items()))
         P = _PARAMS.get(key)
         _PARAMS_STATS[P is None] += 1
         if P is None:

@@ -582,6 +582,28 @@ def test_conv2d_replicate_pad_and_batched_gemm(backend):
     assert (vol.cpu()[:, 0].double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
 
 
+def test_parameter_block_cache_keys_on_the_layer_not_on_the_object(emu_lib):
+    """r05 (ops.conv2d caches the filled pp_conv2d_params block of a launch): two layers that share EVERY buffer -- weights, bias,
+    input, output -- and differ in geometry only must not share a block.  (The first key carried id(spec) + the weight address: a
+    test that builds layers one after the other got the same id and the same addresses back for another geometry, on the MI355X.)"""
+    import dataclasses
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 9, 10, 32, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.1
+    b = torch.randn(32, generator=g)
+    spec = ops.make_conv_spec(w, b, torch.float32, padding=1, split=True)
+    out = torch.empty(1, 9, 10, 32)
+    ops.conv2d(spec, [x], out)
+    zeros = out.clone()
+    twin = dataclasses.replace(spec, pad_mode="replicate", geometry_key=None)      # same tensors, other padding
+    ops.conv2d(twin, [x], out)
+    ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="replicate"), w, b).permute(0, 2, 3, 1)
+    assert (out - ref).abs().max().item() < 1e-4 and (out - zeros).abs().max().item() > 1e-2
+    ops.conv2d(spec, [x], out)
+    assert torch.equal(out, zeros)
+
+
 if __name__ == "__main__":  # child process of test_conv2d_matches_torch
     import os
     import sys
