@@ -46,7 +46,10 @@ Tolerances (north_star: PSNR >= 40 dB on the pixels, masks / schedules bit-exact
   plan the 8-GPU run shards); cfg5_160f_node = configs[4] in full, 160 frames of 1280x720, nl 20; cfg5_90f_contractive_node =
   configs[4]'s size and mode with the contractive weights (completed flows pointwise inside the hole at 1280x720).  Stored for a
   subset of the frames (every k-th + both sides of every sub-video seam; the other frames by the sum of their masked pixels:
-  tests/golden/make_golden.py keep_every), minted without the oracle pin (the fixture IS the reference's output).
+  tests/golden/make_golden.py keep_every), minted without the oracle pin (the fixture IS the reference's output).  Measured on the
+  MI355X (profiles/r05_pytest_gpu.log, r05_pytest_cfg5_160f.log, r05_pytest_cfg5_contractive.log): 640 f 57.5 / 61.4 dB max 2 LSB;
+  160 f 1280x720 57.8 / 63.8 dB max 3 / 2 LSB; contractive 1280x720: completed flows 3.1e-2 / 1.56e-2 px max inside the hole,
+  58.1 / 77.1 dB max 1 LSB.
 A live-oracle case covers configs[4]'s geometry (1280x720, nl 20: 60x107 -> 60x108 token grid, 405 pooled keys)."""
 import json
 from pathlib import Path
