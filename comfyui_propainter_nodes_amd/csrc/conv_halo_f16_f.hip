@@ -1,0 +1,7 @@
+// conv_halo_f16_f.hip -- the f16 halo-tile kernels with fp32 output (conv_halo_f16_kernel.h), one translation unit per storage type
+#include "conv_halo_f16_kernel.h"
+
+namespace pp {
+int launch_halo_f16_f(void* stream, const ConvK& k, int Z) { return launch_halo_f16_t<float>(stream, k, Z); }
+int launch_halo_f16_small_f(void* stream, const ConvK& k, int Z, const HaloGeom& g) { return launch_halo_f16_small_t<float>(stream, k, Z, g); }
+}  // namespace pp

@@ -9,13 +9,13 @@ if [ "${1:-}" = "--build" ]; then
   SRC=$(tools/ablate_src.sh) || exit 1
   for m in 1 2 4 6 16 32; do
     mkdir -p tools/ablate/$m
-    for f in conv_halo conv_halo_f16; do
+    for f in conv_halo conv_halo_f16_h conv_halo_f16_f; do
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPP_ABLATE=$m -I $SRC -I include -c $SRC/$f.hip -o tools/ablate/$m/$f.o &
     done
   done; wait
   for m in 1 2 4 6 16 32; do
-    objs=$(ls $PKG/build/hip/*.o | grep -v "conv_halo.o\|conv_halo_f16.o")
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs tools/ablate/$m/conv_halo.o tools/ablate/$m/conv_halo_f16.o -o tools/ablate/$m/libpropainter_mi355.so && rm tools/ablate/$m/*.o
+    objs=$(ls $PKG/build/hip/*.o | grep -v "conv_halo.o\|conv_halo_f16_h.o\|conv_halo_f16_f.o")
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs tools/ablate/$m/conv_halo.o tools/ablate/$m/conv_halo_f16_h.o tools/ablate/$m/conv_halo_f16_f.o -o tools/ablate/$m/libpropainter_mi355.so && rm tools/ablate/$m/*.o
   done; ls -la tools/ablate/*/; exit 0
 fi
 O=gpurun_out/ablate_halo; mkdir -p $O
