@@ -1,4 +1,7 @@
 #!/bin/bash
+# (r05 end: the build hooks this script times -- PP_HALO_TRIM64 / PP_HALO_WMID / PP_EPI_STORE_MODE -- were measured and removed from csrc/;
+#  TRIM64 is archived in tools/experiments/r05_halo_hooks.patch, the other two are in git history.  Kept as the record of how
+#  profiles/r05_ab_*.log and r05_halo_trace_call1_r04_kernel.log were produced.)
 # r05 GPU call 1: (1) does the matrix pipe honour f16 subnormal inputs (tools/probes/mfma_denorm); (2) the occupancy A/B prepared at
 # the end of r04 (trim64 = three work-groups per CU) and the mid-burst weight copy (wmid) against the product, C++ client, outputs
 # hashed; (3) the s_memtime phase trace of the PP_F32X2 halo kernels (tools/variants/trace.so), two work-groups per CU and solo;

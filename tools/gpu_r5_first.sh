@@ -1,4 +1,7 @@
 #!/bin/bash
+# (r05 end: the build hooks this script times -- PP_HALO_TRIM64 / PP_HALO_WMID / PP_EPI_STORE_MODE -- were measured and removed from csrc/;
+#  TRIM64 is archived in tools/experiments/r05_halo_hooks.patch, the other two are in git history.  Kept as the record of how
+#  profiles/r05_ab_*.log and r05_halo_trace_call1_r04_kernel.log were produced.)
 # First GPU call of the next round (prepared at the end of r04, when the GPU budget was spent): the occupancy A/B that the r04 SQ
 # counters point at (profiles/r04_conv_counters.md: matrix pipe 53-61 % busy at 2 waves per SIMD; one lock-step work-group per CU
 # loses, profiles/r04_ab_w8.log).  Variant `trim64` = csrc/conv_halo.hip built with -DPP_HALO_TRIM64: every PP_F32X2 halo layer on
