@@ -38,8 +38,9 @@ enum pp_dtype {
   PP_U8 = 2,
   PP_I32 = 3,
   /* pp_conv2d only: f32 tensors multiplied on the f16 matrix pipe with two-term operand splits
-   * (v = h + l/2048, three MFMAs per product, fp32 accumulate: fp32-GEMM accuracy for |v| < 32752; above that
-   * the low term saturates: absolute error <= 0.016 up to |v| = 65504, values beyond saturate at +-65536, never Inf/NaN).
+   * (v = h + l, h = f16_rtz(v), l = f16_rtz(v - h) -- r05 / ABI v9: the low term is UNSCALED, the matrix pipe honours f16
+   * subnormals --, three MFMAs per product into one fp32 accumulator: |v - h - l| <= max(2^-20 |v|, 2^-24); beyond the f16
+   * range both terms saturate: |v| <= 131008 is representable to <= 32 absolute, larger values saturate, never Inf/NaN).
    * Weights must be in the split packing described at pp_conv2d. */
   PP_F32X2 = 4
 };
@@ -88,8 +89,9 @@ void pp_reload_options(void);
  * Weights are pre-packed by the host (weights.py: pack_conv_weight):
  *   w[z][cout][tap = ky*kw+kx][seg][c padded to a multiple of 32], dtype = `dtype`.
  * PP_F32X2: inputs / bias / outputs are f32; every 32-channel chunk of the f32 packing (128
- * bytes) is replaced by 32 f16 values h = f16(w) followed by 32 f16 values l = f16((w - h) * 2048)
- * (ops.py: split_pack_weight); same byte size and chunk order as the f32 packing.
+ * bytes) is replaced by 32 f16 values h = f16(S w) followed by 32 f16 values l = f16(S w - h), S a power of two per layer
+ * chosen by the packer (ops.py: split_pack_weight; 1 / S travels as `acc_scale`, ABI v9); same byte size and chunk order as the
+ * f32 packing.
  * gridDim.z = Z selects a group (grouped conv) or a batch item (batched GEMM):
  * every pointer advances by its *_zoff (in elements) per z.
  * ---------------------------------------------------------------------------------- */
