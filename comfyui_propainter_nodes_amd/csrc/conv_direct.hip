@@ -49,7 +49,9 @@ __global__ void __launch_bounds__(256) conv_small_cout_kernel(const ConvK p, con
       w = 0.f;                                   // (COUT is 2 or 4: a 3-channel layer has no fourth weight row)
     } else if (wmode == PP_F32X2) {
       const half_t* row = reinterpret_cast<const half_t*>(reinterpret_cast<const float*>(p.weight) + (int64_t)co * p.Kp + tk * 32);
-      w = (float)row[j] + (float)row[32 + j] * (1.f / 2048.f);
+      // ABI v9 packing: h = f16(S w), l = f16(S w - h) UNSCALED, S = 1 / acc_scale a power of two per layer (this
+      // decoder still read the r04 form, l x 2^-11 and no acc_scale, so a table-less PP_F32X2 launch returned S x the result)
+      w = ((float)row[j] + (float)row[32 + j]) * (p.acc_scale != 0.f ? p.acc_scale : 1.f);
     } else if (wmode == PP_F16) {
       w = (float)reinterpret_cast<const half_t*>(p.weight)[(int64_t)co * p.Kp + tk * 32 + j];
     } else {

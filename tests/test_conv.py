@@ -646,11 +646,16 @@ def test_direct_small_cout_kernel(backend, pp_knobs):
     acts = {None: lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2), "sigmoid": torch.sigmoid, "tanh": torch.tanh}
 
     # RAFT flow head: f32 tensors, PP_F32X2 and exact packings, delta added onto the flow in place
-    for split in (True, False):
+    # (r06, ADVICE r05: also WITHOUT the optional fp32 weight table -- PP_CONV_DIRECT_TABLE=0, or a C-ABI caller that leaves
+    #  weight_f32 NULL: the kernel then decodes the packed weights itself, for PP_F32X2 the ABI v9 form h + l with acc_scale)
+    for split, table in ((True, True), (False, True), (True, False), (False, False)):
         x = torch.randn(2, 19, 37, 256, generator=g)
         w = torch.randn(2, 256, 3, 3, generator=g) * 0.05
         b = torch.randn(2, generator=g)
+        pp_knobs(PP_CONV_DIRECT_TABLE="1" if table else "0")
         spec = ops.make_conv_spec(w, b, torch.float32, padding=1, split=split).to(dev)
+        assert (spec.weight_f32 is not None) == table
+        pp_knobs(PP_CONV_DIRECT_TABLE="1")
         flow0 = torch.randn(2, 19, 37, 2, generator=g)
         flow = flow0.clone().to(dev)
         ops.conv2d(spec, [x.to(dev)], flow, epi="add", aux1=flow)
