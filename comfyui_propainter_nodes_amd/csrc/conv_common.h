@@ -714,5 +714,8 @@ int launch_gemm_f16(void* stream, const ConvK& k, int Z, bool out_f16);
 int launch_gemm_f16_patch(void* stream, const ConvK& k, int Z, bool out_f16);
 // conv_direct.hip: at most 4 output channels, streaming fp32-FMA kernel; returns 1 when not eligible
 int launch_direct_small_cout(void* stream, const ConvK& k, int Z, int dtype, bool out_f16);
+// conv_patch.hip (r06): PP_F32X2 + flat_taps -- f32 input of at most 4 channels (RAFT's 7x7 convolutions on the flow / the frames),
+// the patch matrix built as MFMA operand fragments in LDS instead of pp_im2col's tensor
+int launch_patch_split(void* stream, const ConvK& k, int Z);
 
 }  // namespace pp

@@ -28,7 +28,10 @@ int convk_from_params(const pp_conv2d_params* p, ConvK* kp, const char* who, boo
   if (p->Z < 1 || p->Z > 65535) return fail2(PP_ERR_BAD_ARG, who, "Z out of range");
   if (p->epi != PP_EPI_NONE && !p->aux1) return fail2(PP_ERR_BAD_ARG, who, "epilogue needs aux1");
   if (p->epi == PP_EPI_GRU && !p->aux2) return fail2(PP_ERR_BAD_ARG, who, "GRU epilogue needs aux2");
-  const int epp = p->dtype == PP_F16 ? 8 : 4;
+  // (r06: the PP_F32X2 patch form -- flat_taps on an f32 input of 1..4 channels, conv_patch.hip -- reads its input with 4-byte
+  //  loads: any channel count, pitch and 4-byte-aligned base)
+  const bool patch32 = p->flat_taps != 0 && p->dtype == PP_F32X2;
+  const int epp = patch32 ? 1 : p->dtype == PP_F16 ? 8 : 4;
   memset(&k, 0, sizeof(k));
   int cpt = 0;
   for (int s = 0; s < p->nseg; ++s) {
@@ -37,7 +40,7 @@ int convk_from_params(const pp_conv2d_params* p, ConvK* kp, const char* who, boo
       return fail2(PP_ERR_BAD_ARG, who, "segment channels must be a positive multiple of 16 bytes");
     if ((p->in_ldc[s] % epp) != 0 || (p->in_zoff[s] % epp) != 0)
       return fail2(PP_ERR_BAD_ARG, who, "segment pitch / z offset must be 16-byte multiples");
-    if (!virtual_input && (reinterpret_cast<uintptr_t>(p->in_ptr[s]) & 15) != 0)
+    if (!virtual_input && (reinterpret_cast<uintptr_t>(p->in_ptr[s]) & (patch32 ? 3 : 15)) != 0)
       return fail2(PP_ERR_BAD_ARG, who, "segment base must be 16-byte aligned");
     k.in_ptr[s] = p->in_ptr[s];
     k.in_C[s] = (int)p->in_C[s];
@@ -59,8 +62,8 @@ int convk_from_params(const pp_conv2d_params* p, ConvK* kp, const char* who, boo
   k.nchunks = cpt * k.kh * k.kw;
   k.flat_taps = p->flat_taps != 0;
   if (k.flat_taps) {  // one (ky, kx, c)-ordered weight row per output channel, padded to 32 at the end only
-    if (p->dtype != PP_F16 || p->nseg != 1 || p->Z != 1 || p->pad_mode == PP_PAD_REPLICATE)
-      return fail2(PP_ERR_UNSUPPORTED, who, "flat_taps: f16, one segment, Z 1, zero padding only");
+    if ((p->dtype != PP_F16 && p->dtype != PP_F32X2) || p->nseg != 1 || p->Z != 1 || p->pad_mode == PP_PAD_REPLICATE)
+      return fail2(PP_ERR_UNSUPPORTED, who, "flat_taps: f16 or PP_F32X2, one segment, Z 1, zero padding only");
     k.nchunks = (int)(((int64_t)k.kh * k.kw * p->in_C[0] + 31) / 32);
   }
   k.Kp = k.nchunks * 32;
@@ -94,7 +97,11 @@ extern "C" int32_t pp_conv2d(void* stream, const pp_conv2d_params* p) {
   const int bad = convk_from_params(p, &k, "pp_conv2d", false);
   if (bad != PP_OK) return bad;
   const int Z = (int)p->Z;
-  if (k.flat_taps && p->dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: flat_taps needs PP_F16");
+  if (k.flat_taps && p->dtype == PP_F32X2) {
+    if (p->out_dtype != PP_F32) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: PP_F32X2 writes f32 only");
+    return launch_patch_split(stream, k, Z);
+  }
+  if (k.flat_taps && p->dtype != PP_F16) return pp_fail(PP_ERR_UNSUPPORTED, "pp_conv2d: flat_taps needs PP_F16 or PP_F32X2");
   if (k.Cout <= 4 && !k.flat_taps && p->dtype == PP_F16) {
     const int rs = launch_halo_f16_small_cout(stream, k, Z, p->out_dtype == PP_F16);
     if (rs != 1) return rs;

@@ -112,8 +112,7 @@ class GpuBackend:
         self.act_dtype = models.inpaint_model.dt   # storage type of encoder features / window outputs on the wire
 
     def raft(self, frames):                     # fp32 [n,H,W,3] -> [2,n-1,H,W,2]
-        ff, fb = self.m.raft_model(frames, self.cfg.raft_iter)
-        return torch.stack([ff, fb], 0)
+        return self.m.raft_model.bidirectional(frames, self.cfg.raft_iter)
 
     def complete(self, flows, masks):           # one chunk incl. halos
         return self.m.flow_model(flows.contiguous(), masks.contiguous())

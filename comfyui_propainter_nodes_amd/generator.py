@@ -44,6 +44,10 @@ class ClipState:
         # (outpaint geometry), of every clip with that geometry
         self.static_masks = False
         self.flags = None
+        # r06: soft-split tokens of the REFERENCE frames, computed once per clip frame (a reference frame enters the transformer
+        # of ~8 windows with the same encoder features, so its tokens are the same every time): frame -> row of ref_tok
+        self.ref_tok = None      # f16 [n, fh, fw, 512]
+        self.ref_row: dict[int, int] = {}
 
 
 class InpaintGeneratorMI355:
@@ -205,23 +209,38 @@ class InpaintGeneratorMI355:
         replayed on static copies of the per-clip tensors (graphs.py)."""
         # (the key carries what the captured launches depend on besides the input shapes: the window set and the form of
         # the deformable convolution, an environment knob)
+        # r06: the rows the sweep reads are gathered (window-minor: row i * nw + j = local frame i of window j) straight into
+        # the captured graph's static inputs, ONE index_select per source tensor and replay; r02-r05 copied the whole clip's
+        # tensors into static twins (enc alone: 295 MB at cfg 2, per window group) and gathered per step inside the graph.
         fused = ops.deform_fused(st.enc.shape[1], st.enc.shape[2])
-        return self._graphs.run(("featprop", tuple(g0s), lt, fused), lambda *t: self._featprop_eager(g0s, lt, *t),
-                                st.enc, st.maskpair, st.flow_f, st.flow_b, st.aux_b, st.aux_f)
-
-    def _featprop_eager(self, g0s: list[int], lt: int, enc, maskpair, flow_f, flow_b, aux_b, aux_f) -> torch.Tensor:
-        dev = enc.device
+        dev = st.enc.device
         nw = len(g0s)
-        _, h, w, _ = enc.shape
+        rows = ops.device_ints([g + i for i in range(lt) for g in g0s], dev)
+        rows1 = ops.device_ints([g + i for i in range(lt - 1) for g in g0s], dev)   # frame g + i: flows_forward[g+i], flows_backward[g+i]
+        srcs = ((st.enc, rows), (st.maskpair, rows), (st.flow_f, rows1), (st.flow_b, rows1), (st.aux_b, rows1), (st.aux_f, rows1))
 
-        def gather(t: torch.Tensor, idx: int) -> torch.Tensor:
-            return t.index_select(0, ops.device_ints([g + idx for g in g0s], dev))  # [nw, ...] rows (plain copy)
+        def fill(bufs):
+            if bufs is None:
+                return [t.index_select(0, ix) for t, ix in srcs]
+            for b, (t, ix) in zip(bufs, srcs):
+                torch.index_select(t, 0, ix, out=b)
+            return bufs
+
+        key = ("featprop", tuple(g0s), lt, fused, tuple(st.enc.shape[1:]), st.enc.dtype)
+        return self._graphs.run_filled(key, lambda *t: self._featprop_eager(nw, lt, *t), fill, dev)
+
+    def _featprop_eager(self, nw: int, lt: int, x, mp, flow_f, flow_b, aux_b, aux_f) -> torch.Tensor:
+        """x [lt*nw,h,w,128], mp [lt*nw,h,w,8]: row i * nw + j = local frame i of window j; flows / aux [(lt-1)*nw, ...]: row
+        i * nw + j = the pair (local frame i, i + 1) of window j."""
+        dev = x.device
+        _, h, w, _ = x.shape
+        x, mp = x.view(lt, nw, h, w, 128), mp.view(lt, nw, h, w, 8)
+        flow_f, flow_b = flow_f.view(max(lt - 1, 0), nw, h, w, 2), flow_b.view(max(lt - 1, 0), nw, h, w, 2)
+        aux_b, aux_f = aux_b.view(max(lt - 1, 0), nw, h, w, 8), aux_f.view(max(lt - 1, 0), nw, h, w, 8)
 
         def buf(c, dt=None):
             return torch.empty(nw, h, w, c, device=dev, dtype=dt or self.dt)
 
-        x = torch.stack([gather(enc, i) for i in range(lt)], 0)            # [lt,nw,h,w,128]
-        mp = torch.stack([gather(maskpair, i) for i in range(lt)], 0)      # [lt,nw,h,w,8]
         t128, u128, warped, aligned = buf(128), buf(128), buf(128), buf(128)
         om = buf(432, torch.float32)
         fused = self.dt == torch.float16 and ops.deform_fused(h, w)
@@ -239,9 +258,9 @@ class InpaintGeneratorMI355:
                     prop = cur
                 else:
                     if name == "backward_1":   # frame g uses flows_forward[g] / aux_b[g]
-                        flow, aux = gather(flow_f, idx), gather(aux_b, idx)
+                        flow, aux = flow_f[idx], aux_b[idx]
                     else:                      # frame g uses flows_backward[g-1] / aux_f[g-1]
-                        flow, aux = gather(flow_b, idx - 1), gather(aux_f, idx - 1)
+                        flow, aux = flow_b[idx - 1], aux_f[idx - 1]
                     ops.flow_warp(prop, flow, warped)
                     ops.conv2d(S["off0"], [cur, warped, aux], t128, act="leaky", act_param=0.1)
                     ops.conv2d(S["off2"], [t128], u128, act="leaky", act_param=0.1)
@@ -318,6 +337,25 @@ class InpaintGeneratorMI355:
                     self._geometry_flags[key] = st.flags
         return st.flags
 
+    def reference_tokens(self, st: ClipState, frames: list[int]) -> torch.Tensor:
+        """The soft-split tokens of clip-state frames `frames` (encoder features -> 7x7 / stride-3 embedding), kept per clip:
+        rows are appended for frames not seen before (pipeline.run_inpainting asks for the whole schedule's reference frames up
+        front: one batched convolution per clip).  -> st.ref_tok, indexed through st.ref_row."""
+        new = [f for f in dict.fromkeys(frames) if f not in st.ref_row]
+        if new:
+            dev = st.enc.device
+            fh, fw = token_grid(*st.enc.shape[1:3])
+            n0 = 0 if st.ref_tok is None else st.ref_tok.shape[0]
+            grown = torch.empty(n0 + len(new), fh, fw, 512, device=dev, dtype=self.dt)
+            if n0:
+                grown[:n0] = st.ref_tok
+            src = st.enc.index_select(0, ops.device_ints(new, dev))
+            ops.conv2d(self.ss, [src], grown[n0:])
+            for i, f in enumerate(new):
+                st.ref_row[f] = n0 + i
+            st.ref_tok = grown
+        return st.ref_tok
+
     def forward_window(self, st: ClipState, nb: list[int], refs: list[int], trace: dict | None = None,
                        local_prop: torch.Tensor | None = None) -> torch.Tensor:
         """One neighbour+reference window -> tanh image of the local frames, f16 [l_t,H,W,4] (3 used).
@@ -325,26 +363,34 @@ class InpaintGeneratorMI355:
         dev = st.enc.device
         lt, t = len(nb), len(nb) + len(refs)
         _, h, w, _ = st.enc.shape
-        feat = torch.empty(t, h, w, 128, device=dev, dtype=self.dt)
         if local_prop is None:
             local_prop = self.propagate_windows(st, [nb])[0]
-        feat[:lt] = local_prop
-        if refs:
-            torch.index_select(st.enc, 0, ops.device_ints(refs, dev), out=feat[lt:])
         fh, fw = token_grid(h, w)
         tok = torch.empty(t, fh, fw, 512, device=dev, dtype=self.dt)
-        ops.conv2d(self.ss, [feat], tok)
+        # r06: soft split (sparse_transformer.py:8-37) of the propagated local frames straight from propagate_windows()'s tensor,
+        # the reference frames' tokens from the per-clip table -- r01-r05 assembled [local | enc[refs]] into a `feat` copy per
+        # window and re-ran the 7x7 / stride-3 embedding on every reference frame of every window (8 x 16 frame-convolutions at
+        # cfg 2 for 8 distinct frames).  A convolution's result per image does not depend on its batch: same tokens.
+        local_prop = local_prop.contiguous()
+        ops.conv2d(self.ss, [local_prop], tok[:lt])
+        if refs:
+            torch.index_select(self.reference_tokens(st, refs), 0,
+                               ops.device_ints([st.ref_row[r] for r in refs], dev), out=tok[lt:])
         flags = self.window_mask_flags(st, nb)
         if trace is not None:
-            trace.update(local_prop=feat[:lt].clone(), tok=tok.clone())
-        tok = self._transformer(tok, (h, w), flags)
+            trace.update(local_prop=local_prop.clone(), tok=tok.clone())
+        # r06: the 8 blocks (~80 launches on fixed shapes) replay as ONE hipGraph per token-tensor shape -- a clip has 2-3 distinct
+        # window lengths; inputs: the tokens (28 MB copy) and the 36 window flags; the result lives in the graph's
+        # static buffer and is consumed by the soft composition right below
+        tok = self._graphs.run(("transformer", h, w, os.environ.get("PP_FC2_UNFOLD", "fused")),
+                               lambda tk, fl: self._transformer(tk, (h, w), fl), tok, flags)
         # soft composition + residual, only for the local frames that are decoded (:443-451)
         emb = torch.empty(lt, fh, fw, 6272, device=dev, dtype=self.dt)
         ops.conv2d(self.sc, [tok[:lt]], emb)
         comp = torch.empty(lt, h, w, 128, device=dev, dtype=self.dt)
         ops.fold(emb.view(lt, fh * fw, 6272), comp, fh, fw, False)
         enc3 = torch.empty(lt, h, w, 128, device=dev, dtype=self.dt)
-        ops.conv2d(self.sc_bias_conv, [comp], enc3, epi="add", aux1=feat[:lt])
+        ops.conv2d(self.sc_bias_conv, [comp], enc3, epi="add", aux1=local_prop)
         if trace is not None:
             trace.update(tok_out=tok, enc3=enc3)
         H, W = st.H, st.W

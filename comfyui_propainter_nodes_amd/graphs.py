@@ -23,7 +23,7 @@ import torch
 
 from . import ops
 
-_MAX_GRAPHS = int(os.environ.get("PP_GRAPH_CACHE", "12"))
+_MAX_GRAPHS = int(os.environ.get("PP_GRAPH_CACHE", "24"))
 _CAPTURE_LOCK = threading.Lock()
 
 
@@ -44,8 +44,11 @@ class GraphCache:
     """key -> captured sweep.  `fn(*inputs)` must be a pure function of its tensor arguments that only launches
     kernels / torch device ops on the current stream (no host synchronisation, no pageable H2D copies)."""
 
-    def __init__(self) -> None:
+    def __init__(self, max_entries: int | None = None) -> None:
+        """`max_entries`: LRU capacity (default PP_GRAPH_CACHE); a captured sweep owns the memory pool of everything it allocates
+        -- RAFT's update block: the all-pairs volume, ~12 GB per clip shape at 640x360 -- so big sweeps get a small cache."""
         self._entries: "OrderedDict[tuple, _Entry]" = OrderedDict()
+        self._max = max_entries or _MAX_GRAPHS
 
     def clear(self) -> None:
         """Drop the captured sweeps and their private memory pools (several GB per clip shape; torch's empty_cache does
@@ -60,10 +63,24 @@ class GraphCache:
         with torch.cuda.device(inputs[0].device):
             return self._run_on_device(key, fn, inputs)
 
-    def _run_on_device(self, key: tuple, fn: Callable, inputs):
+    def run_filled(self, key: tuple, fn: Callable, fill: Callable, device: torch.device):
+        """Like run(), for a sweep whose inputs are GATHERED from larger tensors (r06): `fill(None)` allocates and returns the
+        list of input tensors, `fill(bufs)` refills a previous list in place.  The capture's static inputs are then written by
+        the gather itself -- run() copies every input into its static twin first (feature propagation: the whole clip's encoder
+        features, 295 MB at cfg 2, per window group, before gathering from that copy inside the graph)."""
+        if (os.environ.get("PP_GRAPHS", "1") == "0" or ops.CONV_PROFILE is not None or device.type != "cuda"
+                or torch.cuda.is_current_stream_capturing()):
+            return fn(*fill(None))
+        with torch.cuda.device(device):
+            return self._run_on_device(key + (str(device),), fn, None, fill)
+
+    def _run_on_device(self, key: tuple, fn: Callable, inputs, fill: Callable | None = None):
         e = self._entries.get(key)
         if e is None:
-            static_in = [torch.empty_like(t, memory_format=torch.contiguous_format).copy_(t) for t in inputs]
+            if fill is not None:
+                static_in = inputs = fill(None)
+            else:
+                static_in = [torch.empty_like(t, memory_format=torch.contiguous_format).copy_(t) for t in inputs]
             # warm-up on a side stream (torch's capture recipe): one-time initialisation (LDS attributes, cached index
             # tensors, allocator growth) must not happen inside the capture
             s = torch.cuda.Stream(inputs[0].device)
@@ -89,11 +106,22 @@ class GraphCache:
                 _CAPTURE_LOCK.release()
             e = _Entry(g, static_in, out)
             self._entries[key] = e
-            while len(self._entries) > _MAX_GRAPHS:
+            while len(self._entries) > self._max:
                 self._entries.popitem(last=False)
+            # r06: the warm-up run and the capture's own bookkeeping may have WRITTEN the static inputs (the transformer updates its
+            # token tensor in place: the first replay ran on the warm-up's output -- 16 dB on the first clip of a process, caught
+            # by tests/test_baseline_configs.py); sweeps that only read their inputs never noticed.  Refill before the first replay.
+            if fill is not None:
+                fill(e.static_in)
+            else:
+                for dst, src in zip(e.static_in, inputs):
+                    dst.copy_(src)
         else:
             self._entries.move_to_end(key)
-            for dst, src in zip(e.static_in, inputs):
-                dst.copy_(src)
+            if fill is not None:
+                fill(e.static_in)
+            else:
+                for dst, src in zip(e.static_in, inputs):
+                    dst.copy_(src)
         e.graph.replay()
         return e.out

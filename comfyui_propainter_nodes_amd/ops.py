@@ -115,9 +115,11 @@ def device_ints(values, device, dtype: torch.dtype = torch.int64) -> torch.Tenso
                         k0, _ = _INT_CACHE.popitem(last=False)
                         _INT_EVENTS.pop(k0, None)
     elif PIN_DEVICE_INTS > 0:
+        # (pin the tensor THIS call hands out, whatever another thread did to the LRU between the lookup above and here
+        #  -- an evicted-and-unpinned tensor's address would be baked into the graph being captured)
         with _INT_LOCK:
-            if key in _INT_CACHE:
-                _INT_PINNED[key] = _INT_CACHE.pop(key)
+            _INT_PINNED[key] = t
+            _INT_CACHE.pop(key, None)
     if ev is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing():
         if ev.query():
             with _INT_LOCK:
@@ -491,6 +493,52 @@ def linear_of_unfold(spec: ConvSpec, x: torch.Tensor, out: torch.Tensor, kernel:
     return out
 
 
+def patch_conv_enabled() -> bool:
+    """PP_CONV_PATCH=0: RAFT's 7x7 convolutions on the flow / the frames as pp_im2col + 1x1 PP_F32X2 again (the r01-r05 form)."""
+    return os.environ.get("PP_CONV_PATCH", "1") != "0"
+
+
+def conv2d_patch(spec: ConvSpec, x: torch.Tensor, out: torch.Tensor, kh: int, kw: int, *, stride: int = 1, padding: int = 0,
+                 **kw_) -> torch.Tensor:
+    """out = conv(x) for an f32 input of at most 4 channels WITHOUT the im2col tensor (r06, conv_patch.hip: PP_F32X2 + flat_taps).
+    `spec` is the PP_F32X2 1x1 ConvSpec over the (ky, kx, c)-ordered patch vector that conv2d(spec, [im2col(x)]) used -- same
+    weights, same three products per multiply-add; x fp32 [N,H,W,C] view (C <= 4, any pitch), out fp32 [N,Ho,Wo,Cout]
+    (Cout 64 / 128).  RAFT: convf1 on the flow (update.py:100-106) and the encoder stems (extractor.py:130-136)."""
+    n, h, w, c = x.shape
+    if x.dtype != torch.float32 or out.dtype != torch.float32 or not spec.split or x.dim() != 4:
+        raise ValueError("conv2d_patch: PP_F32X2 layers on fp32 tensors only")
+    if x.stride(3) != 1 and c > 1:
+        raise ValueError("conv2d_patch: channel dim must be unit-stride")
+    ldc = x.stride(2)
+    if (h > 1 and x.stride(1) != w * ldc) or (n > 1 and x.stride(0) != h * w * ldc):
+        raise ValueError("conv2d_patch: rows / images must be dense")
+    if spec.kh != 1 or spec.kw != 1 or spec.groups != 1 or len(spec.seg_channels) != 1 or spec.cin_valid != kh * kw * c:
+        raise ValueError(f"conv2d_patch: the layer expects {spec.cin_valid} patch elements, the patches hold {kh * kw * c}")
+    ho, wo = (h + 2 * padding - kh) // stride + 1, (w + 2 * padding - kw) // stride + 1
+    on, oh, ow, oc, oldc = nhwc_view(out)
+    if (on, oh, ow) != (n, ho, wo) or oc < spec.cout:
+        raise ValueError(f"conv2d_patch: bad output view {tuple(out.shape)} for {(n, ho, wo, spec.cout)}")
+    meta = torch.empty(n, ho, wo, spec.seg_channels[0], device="meta", dtype=x.dtype)
+    check_device(x)
+    P = _conv2d_params(spec, [meta], out, virtual_input=True, **kw_)
+    P.in_ptr[0] = x.data_ptr()
+    P.in_C[0], P.in_ldc[0] = c, ldc
+    P.H, P.W = h, w
+    P.kh, P.kw = kh, kw
+    P.sh = P.sw = stride
+    P.ph = P.pw = padding
+    P.flat_taps = 1
+    L = _lib.current()
+    if CONV_PROFILE is not None and out.is_cuda:
+        flops = 2.0 * n * ho * wo * spec.cout * spec.cin_valid
+        key = "f32x2" + (f"|patch{kh}x{kw}s{stride} cin{c} cout{spec.cout} g1 M{n * ho * wo}" if CONV_PROFILE.detailed else "")
+        nbytes = (x.numel() + spec.weight.numel() + n * ho * wo * spec.cout) * 4.0
+        CONV_PROFILE.launch(key, flops, lambda: L.call("pp_conv2d", stream_handle(out), P), nbytes)
+    else:
+        L.call("pp_conv2d", stream_handle(out), P)
+    return out
+
+
 def split_pack(b: torch.Tensor) -> torch.Tensor:
     """fp32 [..., K] (K % 32 == 0, dense) -> the PP_F32X2 weight packing of the same shape (an f32-typed bit container)."""
     check_device(b)
@@ -504,16 +552,18 @@ def split_pack(b: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float = 0.0, split: bool = False) -> torch.Tensor:
+def batched_gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float = 0.0, split: bool = False,
+                    b_packed: bool = False) -> torch.Tensor:
     """out[z, 0, m, n] = scale * sum_k a[z, 0, m, k] * b[z, n, k]  (pp_conv2d with gridDim.z = batch).
 
     a: [Z, 1, M, K] channels-last "image" of M pixels, b: [Z, N, K] per-batch "weights"
     (K a multiple of 32), out: [Z, 1, M, N].  Used for the RAFT all-pairs volume (corr.py:52-60).
-    `split` (fp32 only): PP_F32X2 products -- b is packed on the device (pp_split_pack), a is split inside the kernel.
+    `split` (fp32 only): PP_F32X2 products -- b is packed on the device (pp_split_pack; `b_packed`: the caller already did),
+    a is split inside the kernel.  a / out may be views with a dense [M, K] / [M, N] image per batch entry.
     """
     L = _lib.current()
     check_device(a, b, out)
-    if split and a.dtype == torch.float32:
+    if split and a.dtype == torch.float32 and not b_packed:
         b = split_pack(b)
     z, one, m, k = a.shape
     zb, n, kb = b.shape
@@ -625,7 +675,16 @@ def tiled_order_index(h: int, w: int, device) -> torch.Tensor:
     ~15k integers at 90x160)."""
     # (ADVICE r04: same hand-over as device_ints -- cached by value, uploaded outside any lock, a later user on another stream
     #  waits for the upload's event)
-    return device_ints(_tiled_order_cached(h, w), device)
+    # (ADVICE r05: device_ints keys on the VALUES -- re-hashing ~15k integers per call; this front cache keys on the geometry.
+    #  Entries are only ever handed out pinned-or-cached tensors of device_ints, so its hand-over rules still apply.)
+    key = (h, w, str(device))
+    t = _TILED_INDEX.get(key)
+    if t is None or torch.cuda.is_current_stream_capturing() or PIN_DEVICE_INTS > 0:
+        t = device_ints(_tiled_order_cached(h, w), device)
+        if len(_TILED_INDEX) > 32:
+            _TILED_INDEX.clear()
+        _TILED_INDEX[key] = t
+    return t
 
 
 @functools.lru_cache(maxsize=16)
@@ -678,6 +737,41 @@ def corr_lookup(pyramid: list, flow: torch.Tensor, out: torch.Tensor) -> torch.T
         CONV_PROFILE.launch("corr_lookup", 0.0, lambda: _call("pp_corr_lookup", out, P), nbytes)
     else:
         _call("pp_corr_lookup", out, P)
+    return out
+
+
+def lookup_fused_enabled() -> bool:
+    """PP_LOOKUP_FUSED=0: pp_corr_lookup + the 1x1 convolution as two launches again (the r01-r05 form)."""
+    return os.environ.get("PP_LOOKUP_FUSED", "1") != "0"
+
+
+def corr_lookup_conv(pyramid: list, flow: torch.Tensor, spec: ConvSpec, out: torch.Tensor, **kw) -> torch.Tensor:
+    """out = act(conv1x1(corr_lookup(pyramid, flow))) in ONE launch (r06, pp_corr_lookup_conv): `spec` is the PP_F32X2 1x1
+    convolution 324 -> 256 (RAFT's convc1, update.py:94-112); pyramid / flow as for corr_lookup(); out fp32 [N,h,w,256] view.
+    The 324-channel lookup tensor is never written."""
+    levels = [(t, t.shape[2], t.shape[3], False) if torch.is_tensor(t) else t for t in pyramid]
+    check_device(*[t for t, _, _, _ in levels], flow)
+    n, h, w, _, fl = nhwc_view(flow)
+    if not spec.split or spec.cin_valid != 324 or spec.cout != 256 or (spec.kh, spec.kw, spec.groups) != (1, 1, 1):
+        raise ValueError("corr_lookup_conv: needs the PP_F32X2 1x1 convolution 324 -> 256")
+    S = _lib.STRUCTS["pp_corr_lookup_params"]()
+    for l, (t, ph, pw, tiled) in enumerate(levels):
+        pitch = tiled_pitch(ph, pw) if tiled else ph * pw
+        if not t.is_contiguous() or t.shape[0] != n or t.numel() != n * h * w * pitch:
+            raise ValueError("corr_lookup_conv: bad pyramid level")
+        S.pyr[l], S.ph[l], S.pw[l], S.tiled[l] = t.data_ptr(), ph, pw, int(tiled)
+    S.flow, S.flow_ldc = flow.data_ptr(), fl
+    S.N, S.h, S.w = n, h, w
+    meta = torch.empty(n, h, w, 324, device="meta", dtype=torch.float32)
+    G = _conv2d_params(spec, [meta], out, virtual_input=True, **kw)
+    L = _lib.current()
+    if CONV_PROFILE is not None and out.is_cuda:
+        # one launch, two roofline entries: the lookup's algorithmic bytes WITHOUT its output tensor, the projection's flops
+        nbytes = float(n * h * w) * (len(levels) * 100 * 4 + 256 * 4) + spec.weight.numel() * 4.0
+        flops = 2.0 * n * h * w * 256 * 324
+        CONV_PROFILE.launch("lookup_conv", flops, lambda: L.call2("pp_corr_lookup_conv", stream_handle(out), S, G), nbytes)
+    else:
+        L.call2("pp_corr_lookup_conv", stream_handle(out), S, G)
     return out
 
 

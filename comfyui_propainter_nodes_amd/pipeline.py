@@ -144,8 +144,7 @@ def models_from_state_dicts(sds: dict, device, fp16: str = "enable", provenance:
 
 def compute_flow(raft_model: RaftFlow, frames: torch.Tensor, config: ProPainterConfig) -> torch.Tensor:
     """frames fp32 [T,H,W,3] -> gt flows fp32 [2,T-1,H,W,2] (forward, backward)."""
-    ff, fb = raft_model(frames, config.raft_iter)
-    return torch.stack([ff, fb], 0)
+    return raft_model.bidirectional(frames, config.raft_iter)     # (r06: no torch.stack of the two directions)
 
 
 def complete_flow(flow_model: FlowCompleter, flows: torch.Tensor, flow_masks_u8: torch.Tensor, subvideo_length: int) -> torch.Tensor:
@@ -185,9 +184,7 @@ def flows_overlapped(models: Models, frames: torch.Tensor, flow_masks_u8: torch.
     for f in range(0, n, sv):
         s, e = max(0, f - pad), min(n, f + sv + pad)
         if e > done:          # the pairs this sub-video still misses
-            ff, fb = models.raft_model(frames[done:e + 1], config.raft_iter)
-            gt[0, done:e] = ff
-            gt[1, done:e] = fb
+            models.raft_model.bidirectional(frames[done:e + 1], config.raft_iter, out=gt[:, done:e])
             done = e
         ready = torch.cuda.Event()
         ready.record(main)
@@ -310,6 +307,7 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     if trace is not None:
         trace.update(gt_flows=gt, pred_flows=pred, updated_frames=updated, updated_masks=upd, pred_imgs=[])
     schedule, spans, table = device_schedule(config)
+    gen.reference_tokens(st, sorted({r for _, refs in schedule for r in refs}))   # one embedding per reference frame of the clip
     props = gen.propagate_windows(st, [nb for nb, _ in schedule])
     mark("feature_propagation(all windows batched)")
     finals = final_ranges(schedule, T) if sink is not None else None

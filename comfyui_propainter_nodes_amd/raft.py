@@ -17,9 +17,11 @@ sample), so only the pair batching is memory-capped (`max_volume_bytes`).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
-from . import ops
+from . import graphs, ops
 
 
 def _strip(sd: dict, prefix: str) -> dict:
@@ -84,15 +86,17 @@ class _Encoder:
         n, H, W, _ = frames.shape
         inst = self.kind == "instance"
         h2, w2 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        cols = torch.empty(n, h2, w2, self.c1_kpad, device=dev)
-        ops.im2col(frames, cols, 7, 7, stride=2, padding=3)
         x = torch.empty(n, h2, w2, 64, device=dev)
-        if inst:
-            ops.conv2d(self.conv1, [cols], x)
-            ops.instnorm(x, x, relu_pre=True)
+        if self.conv1.split and ops.patch_conv_enabled():
+            # r06: the 7x7 / stride-2 stem gathers its patches from the 3-channel frames itself (conv_patch.hip): no im2col tensor
+            ops.conv2d_patch(self.conv1, frames, x, 7, 7, stride=2, padding=3, act=None if inst else "relu")
         else:
-            ops.conv2d(self.conv1, [cols], x, act="relu")
-        del cols
+            cols = torch.empty(n, h2, w2, self.c1_kpad, device=dev)
+            ops.im2col(frames, cols, 7, 7, stride=2, padding=3)
+            ops.conv2d(self.conv1, [cols], x, act=None if inst else "relu")
+            del cols
+        if inst:
+            ops.instnorm(x, x, relu_pre=True)
         for blk in self.blocks:
             _, h, w, _ = x.shape
             ho, wo = blk["c1"].out_hw(h, w)
@@ -128,6 +132,7 @@ class RaftFlow:
         self.device = torch.device(device)
         self.max_volume_bytes = max_volume_bytes
         self.enc_chunk = enc_chunk
+        self._graphs = graphs.GraphCache(max_entries=3)   # (each holds the all-pairs volume of its clip shape)
         dt = torch.float32
         self.fnet = _Encoder(_strip(sd, "fnet."), "instance", device)
         self.cnet = _Encoder(_strip(sd, "cnet."), "batch", device)
@@ -164,33 +169,49 @@ class RaftFlow:
         self.mask2 = spec("mask.2")
 
     # ------------------------------------------------------------------------------------
-    def encode(self, frames: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
-        """frames [T,H,W,3] fp32 in [-1,1] -> (fmap [T,h8,w8,256], ctx [T,h8,w8,256] = tanh|relu)."""
+    def encode(self, frames: torch.Tensor, fmap: torch.Tensor | None = None,
+               ctx: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """frames [T,H,W,3] fp32 in [-1,1] -> (fmap [T,h8,w8,256], ctx [T,h8,w8,256] = tanh|relu); written into `fmap` / `ctx`
+        when given."""
         T, H, W, _ = frames.shape
         h8, w8 = H // 8, W // 8
-        fmap = torch.empty(T, h8, w8, 256, device=frames.device)
-        ctx = torch.empty(T, h8, w8, 256, device=frames.device)
+        if fmap is None:
+            fmap = torch.empty(T, h8, w8, 256, device=frames.device)
+        if ctx is None:
+            ctx = torch.empty(T, h8, w8, 256, device=frames.device)
         for s in range(0, T, self.enc_chunk):
             e = min(T, s + self.enc_chunk)
             self.fnet(frames[s:e], fmap[s:e], split_tanh_relu=False)
             self.cnet(frames[s:e], ctx[s:e], split_tanh_relu=True)
         return fmap, ctx
 
-    def _update_pairs(self, f1, f2, ctx, iters: int, flow_up: torch.Tensor, trace: dict | None = None) -> None:
-        """One batch of pair-directions: f1,f2 [P,hw,256], ctx [P,h,w,256] -> flow_up [P,8h,8w,2]."""
-        dev = f1.device
+    def _update_pairs(self, fm, ctx, iters: int, flow_up: tuple, trace: dict | None = None) -> None:
+        """One batch of pair-directions over the n + 1 frames of `fm` [n+1,hw,256]: the n forward pairs (i -> i+1) then the n
+        backward pairs (i+1 -> i); ctx [2n,h,w,256] (context of each pair's first frame) -> flow_up = (forward [n,8h,8w,2],
+        backward [n,8h,8w,2]) views that receive the upsampled flows."""
+        dev = fm.device
         P, h, w, _ = ctx.shape
+        n = P // 2
         hw = h * w
         # corr.py:52-60 (/sqrt(256)); both operands are activations: f2 is split-packed on the device (PP_F32X2).
         # Levels 0 and 1 of the pyramid are stored in 4 x 8 tiles of 128 bytes (r03): a 12 x 12 lookup window then touches
         # ~9 cache lines instead of ~17 on 320-byte rows (r02: 2.0x the algorithmic HBM traffic).  The all-pairs GEMM
         # writes that layout for free: the pixels of f2 (the GEMM's output-channel index) are put in tile order first
         # (zero rows for the tile padding: 45 -> 48 rows at 640x360); the small levels 2 and 3 stay row-major.
+        # r06: the second operand is tile-ordered (and split-packed) ONCE per frame, and the forward / backward halves are two
+        # launches on views of the per-frame tensors -- r01-r05 materialised cat(f1), cat(f2), cat(f2, zero row) (3 x 582 MB at
+        # cfg 2) and tile-ordered / packed every frame twice.  Same GEMMs on the same values.
         pitch0 = ops.tiled_pitch(h, w)
-        f2z = torch.cat([f2, torch.zeros(P, 1, 256, device=dev)], 1)
-        f2t = f2z.index_select(1, ops.tiled_order_index(h, w, dev))
+        split = ops.f32_split_enabled()
+        fz = torch.cat([fm, torch.zeros(n + 1, 1, 256, device=dev)], 1)
+        ft = fz.index_select(1, ops.tiled_order_index(h, w, dev))           # [n+1, pitch0, 256]
+        del fz
+        if split:
+            ft = ops.split_pack(ft)
         vol = torch.empty(P, 1, hw, pitch0, device=dev)
-        ops.batched_gemm_nt(f1.view(P, 1, hw, 256), f2t, vol, scale=1.0 / 16.0, split=ops.f32_split_enabled())
+        ops.batched_gemm_nt(fm[:n].view(n, 1, hw, 256), ft[1:], vol[:n], scale=1.0 / 16.0, split=split, b_packed=split)
+        ops.batched_gemm_nt(fm[1:].view(n, 1, hw, 256), ft[:n], vol[n:], scale=1.0 / 16.0, split=split, b_packed=split)
+        del ft
         pyr = [(vol.view(P, hw, pitch0), h, w, True)]
         for lvl in range(1, 4):
             _, hi, wi, ti = pyr[-1]
@@ -201,10 +222,12 @@ class RaftFlow:
         # 324 lookup channels at a pitch of 352 floats: every 32-channel chunk (128 bytes) the motion encoder's first
         # convolution gathers then starts on a cache-line boundary (at pitch 324 each chunk straddled two lines: that 1x1
         # convolution ran at 120 TF/s where its neighbours reach 250-300)
-        corr = torch.empty(P, h, w, 352, device=dev)[..., :324]
+        fused_lookup = self.convc1.split and ops.lookup_fused_enabled() and trace is None
+        corr = None if fused_lookup else torch.empty(P, h, w, 352, device=dev)[..., :324]
         cor1 = torch.empty(P, h, w, 256, device=dev)
         cf = torch.empty(P, h, w, 256, device=dev)       # cor (192) | flo (64)
-        fcols = torch.empty(P, h, w, self.f1_kpad, device=dev)
+        patch = self.convf1.split and ops.patch_conv_enabled()
+        fcols = None if patch else torch.empty(P, h, w, self.f1_kpad, device=dev)
         flo1 = torch.empty(P, h, w, 128, device=dev)
         mf = torch.zeros(P, h, w, 128, device=dev)       # motion (126) | flow (2)
         flow = mf[..., 126:128]
@@ -219,13 +242,19 @@ class RaftFlow:
         for key, sp in self.gru_ctx.items():
             ctx_term[key] = ops.conv2d(sp, [inp], torch.empty(P, h, w, sp.cout, device=dev))
         for it in range(iters):
-            ops.corr_lookup(pyr, flow, corr)
-            if trace is not None and it == 0:
-                trace["corr0"] = corr.clone()
-            ops.conv2d(self.convc1, [corr], cor1, act="relu")
+            if fused_lookup:   # r06: lookup + convc1 in one launch, the 324-channel tensor never written (corr_lookup_conv.hip)
+                ops.corr_lookup_conv(pyr, flow, self.convc1, cor1, act="relu")
+            else:
+                ops.corr_lookup(pyr, flow, corr)
+                if trace is not None and it == 0:
+                    trace["corr0"] = corr.clone()
+                ops.conv2d(self.convc1, [corr], cor1, act="relu")
             ops.conv2d(self.convc2, [cor1], cf[..., 0:192], act="relu")
-            ops.im2col(flow, fcols, 7, 7, padding=3)
-            ops.conv2d(self.convf1, [fcols], flo1, act="relu")
+            if patch:   # r06: 7x7 on the 2-channel flow without the 291 MB patch tensor per iteration (conv_patch.hip)
+                ops.conv2d_patch(self.convf1, flow, flo1, 7, 7, padding=3, act="relu")
+            else:
+                ops.im2col(flow, fcols, 7, 7, padding=3)
+                ops.conv2d(self.convf1, [fcols], flo1, act="relu")
             ops.conv2d(self.convf2, [flo1], cf[..., 192:256], act="relu")
             ops.conv2d(self.conv, [cf], mf[..., 0:126], act="relu")
             for sfx, hout in (("1", hA), ("2", hB)):
@@ -240,15 +269,56 @@ class RaftFlow:
         ops.conv2d(self.mask0, [hcur], t256, act="relu")
         mask = torch.empty(P, h, w, 576, device=dev)
         ops.conv2d(self.mask2, [t256], mask, out_scale=0.25)           # update.py:153
-        ops.convex_upsample(mask, flow, flow_up)
+        ops.convex_upsample(mask[:n], flow[:n], flow_up[0])            # straight into the caller's [2, T-1, H, W, 2] tensor
+        ops.convex_upsample(mask[n:], flow[n:], flow_up[1])
         if trace is not None:
             trace.update(flow_lr=flow.clone(), net=hcur.clone(), mask=mask)
 
+    def _bidirectional_graph(self, frames: torch.Tensor, iters: int, out: torch.Tensor | None) -> torch.Tensor:
+        """r06: a clip whose pairs fit ONE batch runs its update block -- the all-pairs volume, the pyramid, `iters`
+        iterations of 19 launches, the mask head and the upsampling: ~400 launches on fixed shapes -- as one hipGraph per
+        (clip shape, iters).  The encoders stay eager and write the graph's static inputs in place (fmap; the per-pair context
+        batch is the same cat the eager path makes), so no input is copied; the flows are copied OUT of the graph's static result
+        (2 x 147 MB at cfg 2): the caller's tensor must survive the next replay (sharded runs keep several clips' flows alive)."""
+        T, H, W, _ = frames.shape
+        h, w, n, dev = H // 8, W // 8, T - 1, frames.device
+
+        def fill(bufs):
+            if bufs is None:
+                fm, cx = torch.empty(T, h * w, 256, device=dev), torch.empty(2 * n, h, w, 256, device=dev)
+            else:
+                fm, cx = bufs
+            _, ctx = self.encode(frames, fm.view(T, h, w, 256))
+            torch.cat([ctx[:n], ctx[1:]], 0, out=cx)
+            return [fm, cx]
+
+        def update(fm, cx):
+            up = torch.empty(2, n, H, W, 2, device=dev)
+            self._update_pairs(fm, cx, iters, (up[0], up[1]))
+            return up
+
+        res = self._graphs.run_filled(("raft_update", iters, T, H, W, ops.f32_split_enabled(), ops.patch_conv_enabled(), ops.lookup_fused_enabled()), update, fill, dev)
+        if out is None:
+            out = torch.empty_like(res)
+        out.copy_(res)
+        return out
+
     def __call__(self, frames: torch.Tensor, iters: int, trace: dict | None = None) -> tuple[torch.Tensor, torch.Tensor]:
         """frames [T,H,W,3] fp32 in [-1,1] (channels-last) -> (flows_fwd, flows_bwd), each [T-1,H,W,2]."""
+        out = self.bidirectional(frames, iters, trace)
+        return out[0], out[1]
+
+    def bidirectional(self, frames: torch.Tensor, iters: int, trace: dict | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+        """frames [T,H,W,3] fp32 in [-1,1] -> flows fp32 [2,T-1,H,W,2] (forward, backward): the layout compute_flow hands on
+        (r06: written in place by the upsampling kernel; `out`: an existing [2,T-1,H,W,2] view to fill)."""
         T, H, W, _ = frames.shape
         if H % 8 or W % 8 or H < 128 or W < 128:
             raise ValueError("RAFT needs H, W multiples of 8 and >= 128 (reference limit, SURVEY.md 9.15)")
+        h, w = H // 8, W // 8
+        per_pair = int(h * w * h * w * 4 * 1.34) + h * w * 4 * 3000
+        if (trace is None and T >= 2 and 2 * per_pair * (T - 1) <= self.max_volume_bytes and frames.is_cuda
+                and os.environ.get("PP_GRAPHS_RAFT", "1") != "0"):
+            return self._bidirectional_graph(frames, iters, out)
         fmap, ctx = self.encode(frames)
         if trace is not None:
             trace.update(fmap=fmap, ctx=ctx)
@@ -256,18 +326,13 @@ class RaftFlow:
         hw = h * w
         fm = fmap.view(T, hw, 256)
         npair = T - 1
-        out = torch.empty(2, npair, H, W, 2, device=frames.device)
+        if out is None:
+            out = torch.empty(2, npair, H, W, 2, device=frames.device)
         per_pair = int(hw * hw * 4 * 1.34) + hw * 4 * 3000
         chunk = max(1, min(npair, self.max_volume_bytes // (2 * per_pair)))
         for s in range(0, npair, chunk):
             e = min(npair, s + chunk)
-            n = e - s
-            # forward pairs (i -> i+1) then backward pairs (i+1 -> i) in ONE batch of 2n
-            f1 = torch.cat([fm[s:e], fm[s + 1:e + 1]], 0)
-            f2 = torch.cat([fm[s + 1:e + 1], fm[s:e]], 0)
+            # forward pairs (i -> i+1) then backward pairs (i+1 -> i) in ONE batch of 2n through the update block
             cx = torch.cat([ctx[s:e], ctx[s + 1:e + 1]], 0)
-            up = torch.empty(2 * n, H, W, 2, device=frames.device)
-            self._update_pairs(f1, f2, cx, iters, up, trace)
-            out[0, s:e] = up[:n]
-            out[1, s:e] = up[n:]
-        return out[0], out[1]
+            self._update_pairs(fm[s:e + 1], cx, iters, (out[0, s:e], out[1, s:e]), trace)
+        return out

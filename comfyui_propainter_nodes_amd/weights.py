@@ -137,7 +137,9 @@ def load_state_dicts(weight_dir: Path | None = None) -> dict[str, dict[str, torc
                 f"{path} not found. Place the ProPainter v0.1.0 release checkpoints "
                 f"({', '.join(FILES.values())}) in {weight_dir}."
             )
-        sd = torch.load(path, map_location="cpu")
+        # weights_only: the checkpoints are plain tensor dictionaries (utils/model_utils.py:20-43 loads them the same way);
+        # a user-supplied file must not be able to run pickled code (VERDICT r05 hygiene)
+        sd = torch.load(path, map_location="cpu", weights_only=True)
         check_state_dict(net, sd)
         out[net] = {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
     return out

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 9
+#define PP_ABI_VERSION 10
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -141,7 +141,11 @@ typedef struct {
                         output channel in (ky, kx, c) order, zero-padded to a multiple of 32 at the END only -- the Linear
                         that consumes F.unfold()'s tap-major patch vectors -- and the kernel gathers the patches itself:
                         conv(x) == linear(unfold(x)) without the unfolded matrix (sparse_transformer.py:413-433: fc2 of the
-                        fusion feed-forward reads the folded 40-channel map, 7x7 / stride 3, instead of a 49x copy) */
+                        fusion feed-forward reads the folded 40-channel map, 7x7 / stride 3, instead of a 49x copy).
+                        (ABI v10) also with PP_F32X2 on an f32 input of 1..4 channels (any pitch, 4-byte aligned), Cout 64 or
+                        128, kh*kw*in_C <= 160, zero padding, any stride: RAFT's 7x7 convolutions on the 2-channel flow
+                        (update.py:100-106, every GRU iteration) and on the 3-channel frames (extractor.py:130-136) without
+                        pp_im2col's patch tensor -- conv_patch.hip builds the patches as MFMA fragments in LDS */
   float acc_scale;   /* (ABI v9, PP_F32X2) the accumulators are multiplied by this before the bias is added; 0 = 1.  The packed
                         weights of a layer carry a power-of-two scale S (ops.split_pack_weight: max|w| S in [8192, 16384), so that
                         the LOW f16 term of every weight is a normal number) and acc_scale = 1 / S undoes it exactly */
@@ -241,6 +245,18 @@ typedef struct {
                        2.0x the algorithmic HBM traffic on row-major planes). */
 } pp_corr_lookup_params;
 int32_t pp_corr_lookup(void* stream, const pp_corr_lookup_params* p);
+
+/* ------------------------------------------------------------------------------------
+ * pp_corr_lookup_conv (ABI v10) -- the lookup FUSED with the motion encoder's first convolution:
+ *   cor = act(convc1(CorrBlock(coords)))   corr.py:29-50 feeding update.py:94-112 (BasicMotionEncoder.convc1, relu),
+ * evaluated every GRU iteration.  `lookup` describes the pyramid and the flow exactly as for pp_corr_lookup (its `out` /
+ * `out_ldc` are ignored: the 324 sampled correlations of a pixel never reach memory -- they are built as the MFMA operand
+ * of the projection in LDS); `conv` is the pp_conv2d block of the 1x1 PP_F32X2 convolution 324 -> 256 over those pixels
+ * (N, H, W = the lookup's N, h, w; in_C[0] = 324, its in_ptr is not read; weight / bias / act / out / epilogue fields as for
+ * pp_conv2d).  Same lookup arithmetic (operation by operation) and the same three-product PP_F32X2 arithmetic as the two
+ * launches it replaces; 737 MB less written and read per iteration at 158 x 45 x 80 pixels.
+ * ---------------------------------------------------------------------------------- */
+int32_t pp_corr_lookup_conv(void* stream, const pp_corr_lookup_params* lookup, const pp_conv2d_params* conv);
 
 /* ------------------------------------------------------------------------------------
  * pp_convex_upsample -- RAFT.upsample_flow (raft.py:81-92): softmax over the 9 taps of

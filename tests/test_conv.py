@@ -718,3 +718,53 @@ def test_direct_small_cout_kernel(backend, pp_knobs):
         cfg = (cin, cout, act, act2, asplit, scale, epi, ext, pre is not None)
         assert (obuf[..., :cout].double().cpu() - v).abs().max().item() <= 3e-5 * max(1.0, v.abs().max().item()), cfg
         assert torch.all(obuf[..., cout:].cpu() == 3.0), cfg
+
+
+def test_patch_conv_f32x2(backend):
+    """r06, conv_patch.hip (pp_conv2d, PP_F32X2 + flat_taps): RAFT's 7x7 convolutions on the 2-channel flow (a channel VIEW of the
+    128-channel motion buffer: pitch 128, 8-byte aligned base) and on the 3-channel frames (stride 2, 64 channels), partial 8 x 16
+    tiles both ways, two images, against float64 torch and against the pp_im2col + 1x1 form it replaces (same weights, same
+    three-product arithmetic: equal to fp32 summation-order noise); then a fused epilogue (relu, in-place add) and the refusals."""
+    dev = backend
+    g = torch.Generator().manual_seed(5)
+    for (n, h, w, c, cout, k, stride, pad, act, view) in ((2, 19, 37, 2, 128, 7, 1, 3, "relu", True), (2, 29, 41, 3, 64, 7, 2, 3, None, False),
+                                                          (1, 8, 16, 2, 128, 7, 1, 3, None, False), (1, 21, 18, 4, 64, 5, 1, 2, "leaky", False),
+                                                          (1, 17, 23, 1, 128, 3, 2, 1, "relu", False)):
+        x = torch.randn(n, h, w, c, generator=g) * 3.0
+        wt = torch.randn(cout, c, k, k, generator=g) * 0.1
+        b = torch.randn(cout, generator=g)
+        kv = k * k * c
+        kpad = ops.pad32(kv)
+        spec = ops.make_conv_spec(wt.permute(0, 2, 3, 1).reshape(cout, kv, 1, 1), b, torch.float32, seg_channels=[kpad],
+                                  seg_valid=[kv], split=True).to(dev)
+        if view:   # the flow as RAFT holds it: channels 126..127 of the motion buffer
+            buf = torch.zeros(n, h, w, 128)
+            buf[..., 126:128] = x
+            xd = buf.to(dev)[..., 126:128]
+        else:
+            xd = x.to(dev)
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        out = torch.full((n, ho, wo, cout), 7.0, device=dev)
+        ops.conv2d_patch(spec, xd, out, k, k, stride=stride, padding=pad, act=act, act_param=0.2)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), b.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+        ref = {None: lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.2)}[act](ref)
+        err = (out.double().cpu() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (n, h, w, c, cout, err)
+        cols = torch.empty(n, ho, wo, kpad, device=dev)
+        ops.im2col(xd, cols, k, k, stride=stride, padding=pad)
+        old = torch.empty(n, ho, wo, cout, device=dev)
+        ops.conv2d(spec, [cols], old, act=act, act_param=0.2)
+        assert (out - old).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    # fused epilogue on the patch path: out = relu(conv + bias) + aux
+    aux = torch.randn(n, ho, wo, cout, generator=g)
+    out2 = torch.empty(n, ho, wo, cout, device=dev)
+    ops.conv2d_patch(spec, xd, out2, k, k, stride=stride, padding=pad, act="relu", epi="add", aux1=aux.to(dev))
+    assert (out2.double().cpu() - (ref + aux.double())).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # refused: more than 4 input channels, Cout other than 64 / 128
+    x5 = torch.randn(1, 9, 9, 5, generator=g).to(dev)
+    sp5 = ops.make_conv_spec(torch.randn(64, 45, 1, 1), None, torch.float32, seg_channels=[64], seg_valid=[45], split=True).to(dev)
+    with pytest.raises(RuntimeError, match="flat_taps"):
+        ops.conv2d_patch(sp5, x5, torch.empty(1, 9, 9, 64, device=dev), 3, 3, padding=1)
+    sp32 = ops.make_conv_spec(torch.randn(32, 18, 1, 1), None, torch.float32, seg_channels=[32], seg_valid=[18], split=True).to(dev)
+    with pytest.raises(RuntimeError, match="flat_taps"):
+        ops.conv2d_patch(sp32, x5[..., :2], torch.empty(1, 9, 9, 32, device=dev), 3, 3, padding=1)

@@ -91,3 +91,56 @@ def test_pyramid_lookup_upsample(backend):
     ops.convex_upsample(mask.to(dev), buf[..., 6:8], up)
     ref_up = OR.convex_upsample(flow.permute(0, 3, 1, 2), mask.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     assert torch.allclose(up.cpu(), ref_up, atol=2e-5 * ref_up.abs().max().item())
+
+
+def test_lookup_fused_with_projection(backend):
+    """r06, pp_corr_lookup_conv: the correlation lookup fused with RAFT's 324 -> 256 projection (convc1 + relu) against the two
+    launches it replaces -- pp_corr_lookup, then the 1x1 PP_F32X2 convolution over its output -- and against float64 torch on the
+    lookup's own values: tiled and row-major pyramids, flows that leave the image, a pixel count that is not a multiple of the
+    32-pixel tile (2 x 17 x 19 = 646 pixels: 21 tiles, the last one ragged), the flow as a channel view of a wider buffer."""
+    dev = backend
+    g = torch.Generator().manual_seed(11)
+    n, h, w = 2, 17, 19
+    hw = h * w
+    vol = torch.randn(n, hw, h, w, generator=g).to(dev)
+    pyr = [vol]
+    for lvl in range(3):
+        ph, pw = pyr[-1].shape[2] // 2, pyr[-1].shape[3] // 2
+        nxt = torch.empty(n, hw, ph, pw, device=dev)
+        ops.avgpool2x2(pyr[-1].view(n * hw, *pyr[-1].shape[2:]), nxt.view(n * hw, ph, pw))
+        pyr.append(nxt)
+    order = torch.tensor(ops.tiled_order(h, w))
+    t0 = torch.cat([vol.cpu().view(n, hw, hw), torch.zeros(n, hw, 1)], 2).index_select(2, order).contiguous().to(dev)
+    tp = [(t0, h, w, True)]
+    for lvl in range(1, 4):
+        _, hi, wi, ti = tp[-1]
+        ho, wo, to = hi // 2, wi // 2, lvl == 1
+        nxt = torch.empty(n, hw, ops.tiled_pitch(ho, wo) if to else ho * wo, device=dev)
+        ops.avgpool2x2(tp[-1][0].view(n * hw, -1), nxt.view(n * hw, -1), hw=(hi, wi), in_tiled=ti, out_tiled=to)
+        tp.append((nxt, ho, wo, to))
+    flow = torch.randn(n, h, w, 2, generator=g) * 5
+    buf = torch.zeros(n, h, w, 128, device=dev)
+    buf[..., 126:128] = flow.to(dev)
+    fl = buf[..., 126:128]
+    wt = torch.randn(256, 324, 1, 1, generator=g) * 0.05
+    b = torch.randn(256, generator=g)
+    spec = ops.make_conv_spec(wt, b, torch.float32, split=True).to(dev)
+    for pyramid in (pyr, tp):
+        corr = torch.empty(n, h, w, 352, device=dev)[..., :324]
+        ops.corr_lookup(pyramid, fl, corr)
+        two = torch.empty(n, h, w, 256, device=dev)
+        ops.conv2d(spec, [corr], two, act="relu")
+        one = torch.full((n, h, w, 256), 7.0, device=dev)
+        ops.corr_lookup_conv(pyramid, fl, spec, one, act="relu")
+        ref = F.relu(corr.double().cpu() @ wt.view(256, 324).double().t() + b.double())
+        scale = max(1.0, ref.abs().max().item())
+        assert (one.double().cpu() - ref).abs().max().item() < 2e-5 * scale
+        assert (one - two).abs().max().item() < 1e-5 * scale      # same products, another summation order
+    # a fused epilogue on the one-launch form (out = relu(...) + aux), and the refusal of any other projection
+    aux = torch.randn(n, h, w, 256, generator=g).to(dev)
+    one2 = torch.empty(n, h, w, 256, device=dev)
+    ops.corr_lookup_conv(tp, fl, spec, one2, act="relu", epi="add", aux1=aux)
+    assert (one2 - (one + aux)).abs().max().item() < 1e-5 * scale
+    bad = ops.make_conv_spec(torch.randn(128, 324, 1, 1), None, torch.float32, split=True).to(dev)
+    with pytest.raises(ValueError):
+        ops.corr_lookup_conv(tp, fl, bad, torch.empty(n, h, w, 128, device=dev))
