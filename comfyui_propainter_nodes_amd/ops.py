@@ -741,8 +741,12 @@ def corr_lookup(pyramid: list, flow: torch.Tensor, out: torch.Tensor) -> torch.T
 
 
 def lookup_fused_enabled() -> bool:
-    """PP_LOOKUP_FUSED=0: pp_corr_lookup + the 1x1 convolution as two launches again (the r01-r05 form)."""
-    return os.environ.get("PP_LOOKUP_FUSED", "1") != "0"
+    """PP_LOOKUP_FUSED=1: RAFT's lookup + convc1 as ONE launch (pp_corr_lookup_conv).  Off by default: measured on the MI355X at
+    158 x 45 x 80 pixels the fused kernel is bit-identical to the two launches and 1.5x SLOWER (1691 vs 647 + 467 us,
+    tools/bench_lookup.py, profiles/r06_lookup_fusion.md) -- a CU cannot hold what the fusion needs at once: the operand fragments
+    of a pixel tile (44 KB per 32 pixels), >= 12 pixels' windows in flight to cover the gather latency (3 KB each; the two-launch
+    lookup runs 32 waves per CU), and a 360 KB weight stream per tile that fits neither registers nor L1."""
+    return os.environ.get("PP_LOOKUP_FUSED", "0") == "1"
 
 
 def corr_lookup_conv(pyramid: list, flow: torch.Tensor, spec: ConvSpec, out: torch.Tensor, **kw) -> torch.Tensor:
