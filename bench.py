@@ -154,7 +154,24 @@ def parity_vs_fixture(timed_out_u8, models, fr_d, fm_d, md_d, cfg, frames_u8, md
     fms = np.unpackbits(g["flow_masks"])[:T * h * w].reshape(T, h, w)[:, ::s, ::s].astype(bool)
     hole = np.stack([fms[:-1], fms[1:]], 0)[:, :, None]
     um = np.unpackbits(g["updated_masks"])[:T * h * w].reshape(T, h, w)
-    return {"vs": "tests/golden/cfg2_80f_node.npz = the reference's own node output on THIS 80-frame clip (CPU fp32, "
+    # r06: the generator output in the FLOAT domain (north_star: max abs diff < 1e-2 on the pixels), where the fixture stores the
+    # reference's own pred_img (tests/golden/cfg2_80f_predimg.npz: two windows, first / middle / last local frame, masked pixels)
+    max_abs_float, n_float = None, 0
+    pf_file = ROOT / "tests" / "golden" / "cfg2_80f_predimg.npz"
+    if pf_file.exists() and tr.get("pred_imgs"):
+        pg = np.load(pf_file)
+        sched = pipeline.window_schedule(cfg)
+        max_abs_float = 0.0
+        for key in pg.files:
+            if key.startswith("w"):
+                wi, i = (int(v[1:]) for v in key.split("_"))
+                mine = tr["pred_imgs"][wi][i].numpy()[sel[sched[wi][0][i]]]
+                dd = np.abs(mine - pg[key].astype(np.float32)) * 0.5
+                max_abs_float, n_float = max(max_abs_float, float(dd.max())), n_float + dd.size
+    return {"max_abs_float": None if max_abs_float is None else round(max_abs_float, 6),
+            "max_abs_float_over": f"{n_float} generator outputs (pixel units [0, 1], before the truncation to bytes) of windows 0 and 7 "
+                                  "against the reference's own pred_img (tests/golden/cfg2_80f_predimg.npz)",
+            "vs": "tests/golden/cfg2_80f_node.npz = the reference's own node output on THIS 80-frame clip (CPU fp32, "
                   f"{float(g['ref_seconds'][0]):.0f} s); frames: the output of the last timed step",
             "psnr_db": round(psnr_u8(got[sel], g["out_masked"]), 2),
             "psnr_over": "pixels inside the dilated mask; outside it the frames equal the input bit for bit: "

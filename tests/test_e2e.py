@@ -64,7 +64,8 @@ def test_pipeline_matches_reference_fixture(hip_lib, monkeypatch, case):
     assert e_pf < 3e-2
     assert frac_m < 5e-3 and frac_f < 5e-3
     assert frac_p < 5e-3 and psnr_p >= 40.0
-    assert psnr_o >= 40.0 and frac_o < 1e-2
+    assert d.max().item() * 0.5 < 1e-2                    # r06: north_star's max abs diff < 1e-2 in pixel units, on every value
+    assert psnr_o >= 40.0 and int(np.abs(out.astype(np.int32) - gold.astype(np.int32)).max()) <= 2   # ... and <= 2 LSB on every byte
 
 
 @pytest.mark.gpu

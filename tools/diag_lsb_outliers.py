@@ -58,6 +58,24 @@ def leg_run(case: str, fp16: str, lsb: int) -> None:
     pos = np.argwhere(diff > lsb)                            # [n, 4] = (t, y, x, c)
     sched = pipeline.window_schedule(pipeline.ProPainterConfig(P["ref_stride"], P["neighbor_length"], P["subvideo_length"],
                                                                P["raft_iter"], fp16, T, torch.device("cpu"), (w, h)))
+    # the completed flows at the fixture's sub-grid (stride s, f16): how far OUR flows are from the reference's around a pixel
+    s_ = P["flow_stride"]
+    fkeep = list(g["flow_keep"]) if "flow_keep" in g.files else list(range(T - 1))
+    ours_pf = det["trace"]["pred_flows"].cpu()[:, :, ::s_, ::s_].permute(0, 1, 4, 2, 3).numpy()     # [2,T-1,2,h/s,w/s]
+    d_pf = np.abs(ours_pf[:, fkeep] - g["pred_flow"].astype(np.float32)).max(axis=2)                 # [2,nkeep,h/s,w/s]
+    print(f"completed-flow difference to the reference over the whole clip (stored sub-grid): max {d_pf.max():.2f} px, "
+          f"{(d_pf > 0.5).mean():.2e} of the grid points beyond 0.5 px")
+
+    def flow_diff_near(t, y, x):
+        out = []
+        for ft in (t - 1, t):
+            if ft in fkeep:
+                k = fkeep.index(ft)
+                yy, xx = min(d_pf.shape[2] - 1, int(round(y / s_))), min(d_pf.shape[3] - 1, int(round(x / s_)))
+                y0, y1, x0, x1 = max(0, yy - 1), yy + 2, max(0, xx - 1), xx + 2
+                out.append(float(d_pf[:, k, y0:y1, x0:x1].max()))
+        return max(out) if out else float("nan")
+
     rows = []
     for t, y, x, c in pos:
         visits = [(wi, nb.index(int(t))) for wi, (nb, _) in enumerate(sched) if int(t) in nb]
@@ -66,7 +84,8 @@ def leg_run(case: str, fp16: str, lsb: int) -> None:
         k = int(md[t].ravel()[: y * w + x].sum())
         rows.append((t, y, x, c, int(out_u8[t, y, x, c]), int(want[t, y, x, c]), k, visits, ours))
         print(f"frame {t} ({y},{x}) ch {c}: ours {out_u8[t, y, x, c]} reference {want[t, y, x, c]}; windows "
-              + ", ".join(f"w{wi}[{i}] {v:.3f}" for (wi, i), v in zip(visits, ours)) + f" -> replay {compose_chain(ours)}")
+              + ", ".join(f"w{wi}[{i}] {v:.3f}" for (wi, i), v in zip(visits, ours)) + f" -> replay {compose_chain(ours)}; "
+              f"completed flows within 1 grid step of the pixel (frames {t - 1}, {t}) differ from the reference's by up to {flow_diff_near(t, y, x):.2f} px")
     out = ROOT / "gpurun_out" / f"outliers_{case}_{fp16}.npz"
     out.parent.mkdir(exist_ok=True)
     np.savez(out, pos=pos, k=np.array([r[6] for r in rows], dtype=np.int64), ours_u8=np.array([r[4] for r in rows]),
