@@ -25,6 +25,19 @@
 
 namespace pp {
 
+// Work-group timeline trace (tools/trace_gemm.sh builds a second copy of this translation unit with -DPP_GEMM_TRACE; not defined in
+// the product build): wave 0 of every work-group stamps s_memtime at its start, after its prologue copies are issued, when the
+// first stage has landed, at the end of the loop and at its end, plus its XCC, into a device array read back by pp_debug_gemm_trace.
+#ifdef PP_GEMM_TRACE
+__device__ unsigned long long pp_gemm_trace_buf[8192 * 6];
+#define PP_GT_NOW(v)                         \
+  __builtin_amdgcn_sched_barrier(0);         \
+  const unsigned long long v = __builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_sched_barrier(0)
+#else
+#define PP_GT_NOW(v)
+#endif
+
 // PATCH (pp_conv2d_params.flat_taps): the pixel operand is F.unfold(x) of a kh x kw / stride / padding patch grid, gathered on
 // the fly -- row m = output position (n, i, j), column k = (ky, kx, c); a 16-byte piece is 8 channels of ONE tap (C % 8 == 0),
 // so its source is either 8 consecutive channels of one input pixel or, outside the image, zeros.  Same chunks in the same
@@ -42,6 +55,7 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
   constexpr int NL = KC * (XPASS + WPASS);  // copies per thread and stage
   static_assert((NST - 2) * NL <= 63, "vmcnt is a 6-bit counter");
 
+  PP_GT_NOW(gt_start);
   T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -159,14 +173,25 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
       if (after == c || (c == NST - 2 && after > c)) pp_wait_vmcnt<c * NL>();
     });
   };
+  PP_GT_NOW(gt_issued);
+#ifdef PP_GEMM_TRACE
+  unsigned long long gt_first = 0;
+#endif
   int st = 0;
   for (int qs = 0; qs < nstages; ++qs) {
     wait_landed(nstages - 1 - qs);
     pp_barrier();  // every wave's part of stage qs is visible; everyone is done reading stage (qs-1) % NST
+#ifdef PP_GEMM_TRACE
+    if (qs == 0) {
+      PP_GT_NOW(gt_f);
+      gt_first = gt_f;
+    }
+#endif
     if (qs + NST - 1 < nstages) dma_stage(st == 0 ? NST - 1 : st - 1);
     compute(st);
     st = st + 1 == NST ? 0 : st + 1;
   }
+  PP_GT_NOW(gt_loop);
 
   EpiCtx<OT> e;
   e.bias = p.bias;
@@ -189,6 +214,16 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
         m0 = p_base + wp * TP * 16 + decltype(bi)::value * 16;
         nvalid = (int)(p.M - m0 < 16 ? p.M - m0 : 16);
       });
+#ifdef PP_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_GT_NOW(gt_end);
+  if (tid == 0 && blockIdx.x < 8192) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* t = pp_gemm_trace_buf + (size_t)blockIdx.x * 6;
+    t[0] = gt_start; t[1] = gt_issued; t[2] = gt_first; t[3] = gt_loop; t[4] = gt_end; t[5] = xcc & 15;
+  }
+#endif
 }
 
 template <typename OT, int WC, int WP, int TC, int TP, int KC, int NST, bool PATCH = false>
@@ -252,3 +287,12 @@ int launch_gemm_f16_patch(void* stream, const ConvK& k, int Z, bool out_f16) {
 }
 
 }  // namespace pp
+
+#ifdef PP_GEMM_TRACE
+// (trace build only) copies the work-group timeline of the LAST conv_gemm_f16_kernel launch to the host: 6 x uint64 per work-group
+extern "C" int32_t pp_debug_gemm_trace(void* host_out, int64_t nwg) {
+  if (nwg > 8192) nwg = 8192;
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pp::pp_gemm_trace_buf), (size_t)nwg * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
