@@ -61,6 +61,7 @@ class InpaintGeneratorMI355:
         self._geometry_flags: dict = {}   # outpaint geometry -> masked-window flags (window_mask_flags)
         self.split = dtype == torch.float32 and ops.f32_split_enabled()
         self._graphs = graphs.GraphCache()
+        self._side = None   # second stream of propagate_windows()
         p = {k: v.float() for k, v in sd.items() if v.is_floating_point()}
         dev = device
 
@@ -197,7 +198,27 @@ class InpaintGeneratorMI355:
         groups: dict[int, list[int]] = {}
         for wi, nb in enumerate(windows):
             groups.setdefault(len(nb), []).append(wi)
+        # r06: a large group runs as two halves next to each other on two streams (PP_FEATPROP_LANES=1: one batch): the sweep
+        # alternates gather-bound kernels (flow warp, deformable sampling) with matrix-bound convolutions, and two independent
+        # halves in flight overlap one's gathers with the other's MFMAs.  A layer's result per window does not depend on its batch
+        # (kernel selection never looks at it): the same bits as one batch.
+        two = (os.environ.get("PP_FEATPROP_LANES", "2") != "1" and st.enc.is_cuda and not torch.cuda.is_current_stream_capturing()
+               and ops.CONV_PROFILE is None)
         for lt, wis in groups.items():
+            if two and len(wis) >= 8:
+                dev = st.enc.device
+                main = torch.cuda.current_stream(dev)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(dev)
+                side, half = self._side, (len(wis) + 1) // 2
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    out_b = self._feature_propagation_batch(st, [windows[wi][0] for wi in wis[half:]], lt)
+                out_a = self._feature_propagation_batch(st, [windows[wi][0] for wi in wis[:half]], lt)
+                main.wait_stream(side)
+                for j, wi in enumerate(wis):
+                    result[wi] = out_a[:, j] if j < half else out_b[:, j - half]
+                continue
             out = self._feature_propagation_batch(st, [windows[wi][0] for wi in wis], lt)
             for j, wi in enumerate(wis):
                 result[wi] = out[:, j]
@@ -357,7 +378,7 @@ class InpaintGeneratorMI355:
         return st.ref_tok
 
     def forward_window(self, st: ClipState, nb: list[int], refs: list[int], trace: dict | None = None,
-                       local_prop: torch.Tensor | None = None) -> torch.Tensor:
+                       local_prop: torch.Tensor | None = None, lane: int = 0) -> torch.Tensor:
         """One neighbour+reference window -> tanh image of the local frames, f16 [l_t,H,W,4] (3 used).
         `local_prop` = this window's entry of propagate_windows() (computed here when not given)."""
         dev = st.enc.device
@@ -382,7 +403,9 @@ class InpaintGeneratorMI355:
         # r06: the 8 blocks (~80 launches on fixed shapes) replay as ONE hipGraph per token-tensor shape -- a clip has 2-3 distinct
         # window lengths; inputs: the tokens (28 MB copy) and the 36 window flags; the result lives in the graph's
         # static buffer and is consumed by the soft composition right below
-        tok = self._graphs.run(("transformer", h, w, os.environ.get("PP_FC2_UNFOLD", "fused")),
+        # (`lane`: two windows in flight on two streams -- pipeline.run_inpainting -- replay two INSTANCES of a shape's graph: a
+        #  captured sweep owns its static buffers)
+        tok = self._graphs.run(("transformer", h, w, os.environ.get("PP_FC2_UNFOLD", "fused"), lane),
                                lambda tk, fl: self._transformer(tk, (h, w), fl), tok, flags)
         # soft composition + residual, only for the local frames that are decoded (:443-451)
         emb = torch.empty(lt, fh, fw, 6272, device=dev, dtype=self.dt)

@@ -539,12 +539,16 @@ def conv2d_patch(spec: ConvSpec, x: torch.Tensor, out: torch.Tensor, kh: int, kw
     return out
 
 
-def split_pack(b: torch.Tensor) -> torch.Tensor:
-    """fp32 [..., K] (K % 32 == 0, dense) -> the PP_F32X2 weight packing of the same shape (an f32-typed bit container)."""
-    check_device(b)
+def split_pack(b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """fp32 [..., K] (K % 32 == 0, dense) -> the PP_F32X2 weight packing of the same shape (an f32-typed bit container; `out`: an
+    existing dense tensor of that shape to fill)."""
+    check_device(b, out)
     if b.dtype != torch.float32 or not b.is_contiguous() or b.shape[-1] % 32:
         raise ValueError("split_pack: expected a dense fp32 tensor with K % 32 == 0")
-    out = torch.empty_like(b)
+    if out is None:
+        out = torch.empty_like(b)
+    elif out.shape != b.shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("split_pack: bad output tensor")
     P = _lib.STRUCTS["pp_split_pack_params"]()
     setattr(P, "in", b.data_ptr())
     P.out, P.rows, P.K = out.data_ptr(), b.numel() // b.shape[-1], b.shape[-1]

@@ -200,8 +200,8 @@ def flows_overlapped(models: Models, frames: torch.Tensor, flow_masks_u8: torch.
 _SIDE_STREAMS: dict = {}
 
 
-def _side_stream(dev) -> "torch.cuda.Stream":
-    key = str(dev)
+def _side_stream(dev, k: int = 1) -> "torch.cuda.Stream":
+    key = (str(dev), k)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
     return _SIDE_STREAMS[key]
@@ -311,14 +311,43 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
     props = gen.propagate_windows(st, [nb for nb, _ in schedule])
     mark("feature_propagation(all windows batched)")
     finals = final_ranges(schedule, T) if sink is not None else None
-    for wi, (nb, refs) in enumerate(schedule):
-        out = gen.forward_window(st, nb, refs, local_prop=props[wi])
+    # r06: windows are independent until the order-dependent uint8 compose, so `lanes` consecutive windows run next to each other
+    # -- the first on the launch stream, the others on side streams (PP_WINDOW_LANES, default 2; 1: one after the other).  The
+    # transformer's GEMMs are identical work-groups that compute together and then write together (profiles/r06_gemm_timeline.md:
+    # the store drain is as long as the K loop); windows in flight interleave one's write bursts with another's matrix work and
+    # fill each other's last rounds.  Same kernels on the same values, the compose stays on the launch stream in window order:
+    # bit-identical (tests/test_e2e.py).
+    lanes = max(1, int(os.environ.get("PP_WINDOW_LANES", "2")))
+    if not (fr_u8.is_cuda and trace is None and not torch.cuda.is_current_stream_capturing() and ops.CONV_PROFILE is None):
+        lanes = 1
+    lanes = min(lanes, len(schedule))
+    main = torch.cuda.current_stream(dev) if lanes > 1 else None
+    sides = [_side_stream(dev, k) for k in range(1, lanes)]
+
+    def finish(wi, out):
         a, b = spans[wi]
         ops.compose_u8(out, table[0, a:b], table[1, a:b], md, fr_u8, comp)
         if trace is not None:
             trace["pred_imgs"].append(out[..., :3].float().cpu())
         if finals is not None and finals[wi][1] > finals[wi][0]:
             sink.frames_final(comp, *finals[wi])     # these frames can no longer change: stream them out
+
+    for w0 in range(0, len(schedule), lanes):
+        group = list(range(w0, min(len(schedule), w0 + lanes)))
+        outs = {}
+        for k, wi in enumerate(group[1:], start=1):
+            side = sides[k - 1]
+            side.wait_stream(main)                   # props / clip state / the previous group's buffers are ready
+            with torch.cuda.stream(side):
+                nb, refs = schedule[wi]
+                outs[wi] = gen.forward_window(st, nb, refs, local_prop=props[wi], lane=k)
+        nb, refs = schedule[w0]
+        outs[w0] = gen.forward_window(st, nb, refs, local_prop=props[w0])
+        for k, wi in enumerate(group):
+            if k > 0:
+                main.wait_stream(sides[k - 1])
+                outs[wi].record_stream(main)
+            finish(wi, outs[wi])
     mark("windows(transformer+decoder+compose)")
     if timing:
         print("[pp] stage ms: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f}" for a, b in zip(marks, marks[1:])), flush=True)

@@ -132,7 +132,9 @@ class RaftFlow:
         self.device = torch.device(device)
         self.max_volume_bytes = max_volume_bytes
         self.enc_chunk = enc_chunk
-        self._graphs = graphs.GraphCache(max_entries=3)   # (each holds the all-pairs volume of its clip shape)
+        self._graphs = graphs.GraphCache(max_entries=6)   # (each holds the all-pairs volume of half a clip shape)
+        self._ws: dict = {}       # per clip shape: the update graphs' static inputs (feature maps, per-pair context, tiled operand)
+        self._side = None         # the second direction's stream
         dt = torch.float32
         self.fnet = _Encoder(_strip(sd, "fnet."), "instance", device)
         self.cnet = _Encoder(_strip(sd, "cnet."), "batch", device)
@@ -179,39 +181,64 @@ class RaftFlow:
             fmap = torch.empty(T, h8, w8, 256, device=frames.device)
         if ctx is None:
             ctx = torch.empty(T, h8, w8, 256, device=frames.device)
+        # r06: the two encoders share nothing but their input: cnet runs on a second stream next to fnet (PP_ENC_LANES=1: one
+        # after the other); fnet's instance-norm passes are bandwidth-bound, cnet's folded-BatchNorm convolutions matrix-bound
+        two = (frames.is_cuda and os.environ.get("PP_ENC_LANES", "2") != "1" and not torch.cuda.is_current_stream_capturing()
+               and ops.CONV_PROFILE is None)
+        if two:
+            main = torch.cuda.current_stream(frames.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(frames.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                for s in range(0, T, self.enc_chunk):
+                    e = min(T, s + self.enc_chunk)
+                    self.cnet(frames[s:e], ctx[s:e], split_tanh_relu=True)
         for s in range(0, T, self.enc_chunk):
             e = min(T, s + self.enc_chunk)
             self.fnet(frames[s:e], fmap[s:e], split_tanh_relu=False)
-            self.cnet(frames[s:e], ctx[s:e], split_tanh_relu=True)
+            if not two:
+                self.cnet(frames[s:e], ctx[s:e], split_tanh_relu=True)
+        if two:
+            main.wait_stream(self._side)
         return fmap, ctx
 
-    def _update_pairs(self, fm, ctx, iters: int, flow_up: tuple, trace: dict | None = None) -> None:
-        """One batch of pair-directions over the n + 1 frames of `fm` [n+1,hw,256]: the n forward pairs (i -> i+1) then the n
-        backward pairs (i+1 -> i); ctx [2n,h,w,256] (context of each pair's first frame) -> flow_up = (forward [n,8h,8w,2],
-        backward [n,8h,8w,2]) views that receive the upsampled flows."""
+    def _tiled_operand(self, fm: torch.Tensor, h: int, w: int, out: tuple | None = None) -> torch.Tensor:
+        """The second operand of the all-pairs GEMM for every frame of fm [n+1,hw,256]: its pixels (the GEMM's output-channel index)
+        in the 4 x 8 tile order of the level-0 planes, zero rows for the tile padding (45 -> 48 rows at 640x360), split-packed for
+        PP_F32X2 -- ONCE per frame (r06; r01-r05 built it per pair-direction from three 582 MB concatenations)."""
+        n1 = fm.shape[0]
+        fz = torch.cat([fm, torch.zeros(n1, 1, 256, device=fm.device)], 1)
+        idx = ops.tiled_order_index(h, w, fm.device)
+        if out is None:
+            ft = fz.index_select(1, idx)                                    # [n+1, pitch0, 256]
+            return ops.split_pack(ft) if ops.f32_split_enabled() else ft
+        gathered, packed = out                                              # (`out`: a graph's static buffers, filled in place)
+        if not ops.f32_split_enabled():
+            return torch.index_select(fz, 1, idx, out=packed)
+        torch.index_select(fz, 1, idx, out=gathered)
+        return ops.split_pack(gathered, out=packed)
+
+    def _update_pairs(self, fm, ft, ctx, iters: int, flow_up: tuple, trace: dict | None = None, direction: int | None = None) -> None:
+        """The update block over the n + 1 frames of `fm` [n+1,hw,256] (`ft` = _tiled_operand(fm)).  direction None: ONE batch of the
+        n forward pairs (i -> i+1) then the n backward pairs (i+1 -> i), ctx [2n,h,w,256] (context of each pair's first frame),
+        flow_up = (forward [n,8h,8w,2], backward [n,8h,8w,2]) views that receive the upsampled flows; direction 0 / 1: that half
+        alone (ctx [n,...], flow_up[direction] written) -- bidirectional() runs the two halves on two streams."""
         dev = fm.device
         P, h, w, _ = ctx.shape
-        n = P // 2
+        n = fm.shape[0] - 1
         hw = h * w
-        # corr.py:52-60 (/sqrt(256)); both operands are activations: f2 is split-packed on the device (PP_F32X2).
+        # corr.py:52-60 (/sqrt(256)); both operands are activations: the second one is split-packed on the device (PP_F32X2).
         # Levels 0 and 1 of the pyramid are stored in 4 x 8 tiles of 128 bytes (r03): a 12 x 12 lookup window then touches
         # ~9 cache lines instead of ~17 on 320-byte rows (r02: 2.0x the algorithmic HBM traffic).  The all-pairs GEMM
-        # writes that layout for free: the pixels of f2 (the GEMM's output-channel index) are put in tile order first
-        # (zero rows for the tile padding: 45 -> 48 rows at 640x360); the small levels 2 and 3 stay row-major.
-        # r06: the second operand is tile-ordered (and split-packed) ONCE per frame, and the forward / backward halves are two
-        # launches on views of the per-frame tensors -- r01-r05 materialised cat(f1), cat(f2), cat(f2, zero row) (3 x 582 MB at
-        # cfg 2) and tile-ordered / packed every frame twice.  Same GEMMs on the same values.
+        # writes that layout for free (its second operand is in tile order); the small levels 2 and 3 stay row-major.
         pitch0 = ops.tiled_pitch(h, w)
         split = ops.f32_split_enabled()
-        fz = torch.cat([fm, torch.zeros(n + 1, 1, 256, device=dev)], 1)
-        ft = fz.index_select(1, ops.tiled_order_index(h, w, dev))           # [n+1, pitch0, 256]
-        del fz
-        if split:
-            ft = ops.split_pack(ft)
         vol = torch.empty(P, 1, hw, pitch0, device=dev)
-        ops.batched_gemm_nt(fm[:n].view(n, 1, hw, 256), ft[1:], vol[:n], scale=1.0 / 16.0, split=split, b_packed=split)
-        ops.batched_gemm_nt(fm[1:].view(n, 1, hw, 256), ft[:n], vol[n:], scale=1.0 / 16.0, split=split, b_packed=split)
-        del ft
+        if direction in (None, 0):
+            ops.batched_gemm_nt(fm[:n].view(n, 1, hw, 256), ft[1:], vol[:n], scale=1.0 / 16.0, split=split, b_packed=split)
+        if direction in (None, 1):
+            ops.batched_gemm_nt(fm[1:].view(n, 1, hw, 256), ft[:n], vol[P - n:], scale=1.0 / 16.0, split=split, b_packed=split)
         pyr = [(vol.view(P, hw, pitch0), h, w, True)]
         for lvl in range(1, 4):
             _, hi, wi, ti = pyr[-1]
@@ -269,38 +296,66 @@ class RaftFlow:
         ops.conv2d(self.mask0, [hcur], t256, act="relu")
         mask = torch.empty(P, h, w, 576, device=dev)
         ops.conv2d(self.mask2, [t256], mask, out_scale=0.25)           # update.py:153
-        ops.convex_upsample(mask[:n], flow[:n], flow_up[0])            # straight into the caller's [2, T-1, H, W, 2] tensor
-        ops.convex_upsample(mask[n:], flow[n:], flow_up[1])
+        if direction in (None, 0):
+            ops.convex_upsample(mask[:n], flow[:n], flow_up[0])        # straight into the caller's [2, T-1, H, W, 2] tensor
+        if direction in (None, 1):
+            ops.convex_upsample(mask[P - n:], flow[P - n:], flow_up[1])
         if trace is not None:
             trace.update(flow_lr=flow.clone(), net=hcur.clone(), mask=mask)
 
     def _bidirectional_graph(self, frames: torch.Tensor, iters: int, out: torch.Tensor | None) -> torch.Tensor:
         """r06: a clip whose pairs fit ONE batch runs its update block -- the all-pairs volume, the pyramid, `iters`
-        iterations of 19 launches, the mask head and the upsampling: ~400 launches on fixed shapes -- as one hipGraph per
-        (clip shape, iters).  The encoders stay eager and write the graph's static inputs in place (fmap; the per-pair context
-        batch is the same cat the eager path makes), so no input is copied; the flows are copied OUT of the graph's static result
-        (2 x 147 MB at cfg 2): the caller's tensor must survive the next replay (sharded runs keep several clips' flows alive)."""
+        iterations of 19 launches, the mask head and the upsampling: ~400 launches on fixed shapes -- as hipGraphs per (clip shape,
+        iters), ONE PER DIRECTION, replayed next to each other on two streams (PP_RAFT_LANES=1: one graph, one stream): like the
+        transformer windows (pipeline.run_inpainting), two independent halves in flight interleave one's store bursts with the
+        other's matrix work; a layer's result per pair does not depend on its batch, so the flows are the same bits.  The encoders
+        stay eager and write the graphs' static inputs (per-shape workspace: feature maps, tile-ordered second operand, per-pair
+        context) in place, so no input is copied; the flows are copied OUT of the graphs' static results (2 x 147 MB at cfg 2):
+        the caller's tensor must survive the next replay (sharded runs keep several clips' flows alive)."""
         T, H, W, _ = frames.shape
         h, w, n, dev = H // 8, W // 8, T - 1, frames.device
-
-        def fill(bufs):
-            if bufs is None:
-                fm, cx = torch.empty(T, h * w, 256, device=dev), torch.empty(2 * n, h, w, 256, device=dev)
-            else:
-                fm, cx = bufs
-            _, ctx = self.encode(frames, fm.view(T, h, w, 256))
-            torch.cat([ctx[:n], ctx[1:]], 0, out=cx)
-            return [fm, cx]
-
-        def update(fm, cx):
-            up = torch.empty(2, n, H, W, 2, device=dev)
-            self._update_pairs(fm, cx, iters, (up[0], up[1]))
-            return up
-
-        res = self._graphs.run_filled(("raft_update", iters, T, H, W, ops.f32_split_enabled(), ops.patch_conv_enabled(), ops.lookup_fused_enabled()), update, fill, dev)
+        key = (T, H, W, ops.f32_split_enabled())
+        ws = self._ws.get(key)
+        if ws is None:
+            while len(self._ws) >= 3:                       # (bounded like the graph cache: a workspace is ~1.2 GB at cfg 2)
+                self._ws.pop(next(iter(self._ws)))
+            pitch0 = ops.tiled_pitch(h, w)
+            ws = self._ws[key] = (torch.empty(T, h * w, 256, device=dev), torch.empty(2 * n, h, w, 256, device=dev),
+                                  torch.empty(T, pitch0, 256, device=dev), torch.empty(T, pitch0, 256, device=dev))
+        fm, cx, ft_gathered, ft = ws
+        _, ctx = self.encode(frames, fm.view(T, h, w, 256))
+        torch.cat([ctx[:n], ctx[1:]], 0, out=cx)
+        self._tiled_operand(fm, h, w, out=(ft_gathered, ft))
+        gkey = ("raft_update", iters, T, H, W, ops.f32_split_enabled(), ops.patch_conv_enabled(), ops.lookup_fused_enabled())
         if out is None:
-            out = torch.empty_like(res)
-        out.copy_(res)
+            out = torch.empty(2, n, H, W, 2, device=dev)
+        if os.environ.get("PP_RAFT_LANES", "2") == "1":
+            def update(fm_, ft_, cx_):
+                up = torch.empty(2, n, H, W, 2, device=dev)
+                self._update_pairs(fm_, ft_, cx_, iters, (up[0], up[1]))
+                return up
+
+            out.copy_(self._graphs.run_filled(gkey + ("both",), update, lambda bufs: [fm, ft, cx], dev))
+            return out
+        main = torch.cuda.current_stream(dev)
+        side = self._side
+        if side is None:
+            side = self._side = torch.cuda.Stream(dev)
+
+        def update_dir(d):
+            def fn(fm_, ft_, cx_):
+                up = torch.empty(n, H, W, 2, device=dev)
+                self._update_pairs(fm_, ft_, cx_, iters, (up, up), direction=d)
+                return up
+            return fn
+
+        side.wait_stream(main)                              # the workspace is written
+        with torch.cuda.stream(side):
+            up1 = self._graphs.run_filled(gkey + (1,), update_dir(1), lambda bufs: [fm, ft, cx[n:]], dev)
+            out[1].copy_(up1)
+        up0 = self._graphs.run_filled(gkey + (0,), update_dir(0), lambda bufs: [fm, ft, cx[:n]], dev)
+        out[0].copy_(up0)
+        main.wait_stream(side)
         return out
 
     def __call__(self, frames: torch.Tensor, iters: int, trace: dict | None = None) -> tuple[torch.Tensor, torch.Tensor]:
@@ -316,8 +371,10 @@ class RaftFlow:
             raise ValueError("RAFT needs H, W multiples of 8 and >= 128 (reference limit, SURVEY.md 9.15)")
         h, w = H // 8, W // 8
         per_pair = int(h * w * h * w * 4 * 1.34) + h * w * 4 * 3000
+        # (not while bench.py times individual launches with HIP events -- ops.CONV_PROFILE: launches that share the chip with a
+        #  second stream cannot be priced one by one)
         if (trace is None and T >= 2 and 2 * per_pair * (T - 1) <= self.max_volume_bytes and frames.is_cuda
-                and os.environ.get("PP_GRAPHS_RAFT", "1") != "0"):
+                and os.environ.get("PP_GRAPHS_RAFT", "1") != "0" and ops.CONV_PROFILE is None):
             return self._bidirectional_graph(frames, iters, out)
         fmap, ctx = self.encode(frames)
         if trace is not None:
@@ -334,5 +391,6 @@ class RaftFlow:
             e = min(npair, s + chunk)
             # forward pairs (i -> i+1) then backward pairs (i+1 -> i) in ONE batch of 2n through the update block
             cx = torch.cat([ctx[s:e], ctx[s + 1:e + 1]], 0)
-            self._update_pairs(fm[s:e + 1], cx, iters, (out[0, s:e], out[1, s:e]), trace)
+            fmc = fm[s:e + 1]
+            self._update_pairs(fmc, self._tiled_operand(fmc, h, w), cx, iters, (out[0, s:e], out[1, s:e]), trace)
         return out

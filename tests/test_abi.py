@@ -13,9 +13,10 @@ def test_header_parses_to_structs_and_functions():
     for f in ("pp_conv2d", "pp_corr_lookup", "pp_deform_cols", "pp_img_prop_step", "pp_window_attention", "pp_compose_u8"):
         assert f in funcs
     # every pp_<op> entry point has a matching pp_<op>_params struct (pp_deform_conv, the fused form of pp_deform_cols +
-    # pp_conv2d, takes the parameter blocks of those two)
+    # pp_conv2d, takes the parameter blocks of those two; r06 pp_corr_lookup_conv those of pp_corr_lookup + pp_conv2d)
+    assert "pp_corr_lookup_conv" in funcs
     for f in funcs:
-        if f not in ("pp_version", "pp_last_error", "pp_struct_size", "pp_reload_options", "pp_deform_conv"):
+        if f not in ("pp_version", "pp_last_error", "pp_struct_size", "pp_reload_options", "pp_deform_conv", "pp_corr_lookup_conv"):
             assert f + "_params" in structs, f
     assert "pp_deform_conv" in funcs
 
