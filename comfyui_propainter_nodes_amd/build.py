@@ -96,7 +96,15 @@ def isa_path(stem: str) -> Path:
 
 
 def build_hip(force: bool = False) -> Path:
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=off",
+    # -fno-slp-vectorize (r06): hipcc's SLP vectoriser pairs scalar fp32 operations into packed VOP3P instructions and, where the
+    # pairs are crossed (deform_cols adds the (x, y) flow to its (dy, dx) offsets), selects the operand halves with `op_sel`:
+    # `v_pk_add_f32 v[2:3], v[2:3], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]`.  On the MI355X that instruction form returns a WRONG
+    # low half for lanes 48..63 of a wave when MFMA instructions of ANOTHER wave share the SIMD -- i.e. whenever such a kernel
+    # runs next to a convolution on a second stream (minimal reproducer, no memory traffic: tools/probes/pk_f32_next_to_mfma.hip;
+    # how it was found: profiles/r06_pk_f32_op_sel_erratum.md).  Without SLP no kernel of the library contains a packed fp32
+    # instruction with an `op_sel` half-swap (the explicit f4 arithmetic of the epilogues only uses the op_sel_hi broadcast forms);
+    # tests/test_isa_audit.py checks the shipped code objects for it.
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=off", "-fno-slp-vectorize",
              "-I", str(CSRC), "-I", str(ROOT / "include")]
 
     def compile_one(src: Path, obj: Path) -> None:

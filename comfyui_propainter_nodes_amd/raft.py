@@ -392,5 +392,18 @@ class RaftFlow:
             # forward pairs (i -> i+1) then backward pairs (i+1 -> i) in ONE batch of 2n through the update block
             cx = torch.cat([ctx[s:e], ctx[s + 1:e + 1]], 0)
             fmc = fm[s:e + 1]
-            self._update_pairs(fmc, self._tiled_operand(fmc, h, w), cx, iters, (out[0, s:e], out[1, s:e]), trace)
+            ft = self._tiled_operand(fmc, h, w)
+            if (trace is None and frames.is_cuda and ops.CONV_PROFILE is None and os.environ.get("PP_RAFT_LANES", "2") != "1"
+                    and not torch.cuda.is_current_stream_capturing()):
+                # the two directions of the chunk next to each other on two streams (as the graph path does for a whole clip)
+                main = torch.cuda.current_stream(frames.device)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(frames.device)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self._update_pairs(fmc, ft, cx[e - s:], iters, (None, out[1, s:e]), direction=1)
+                self._update_pairs(fmc, ft, cx[:e - s], iters, (out[0, s:e], None), direction=0)
+                main.wait_stream(self._side)
+            else:
+                self._update_pairs(fmc, ft, cx, iters, (out[0, s:e], out[1, s:e]), trace)
         return out

@@ -116,3 +116,32 @@ def test_epilogue_forms_are_bit_identical_end_to_end(hip_lib, pp_knobs, fp16):
     ops._PARAMS.clear()
     direct = pipeline.run_inpainting(models, g["frames_u8"], g["flow_masks"], g["masks_dilated"], cfg)
     assert torch.equal(lean, direct)
+
+
+@pytest.mark.gpu
+def test_stream_lanes_are_bit_identical_and_reproducible(hip_lib, monkeypatch):
+    """r06: the stream lanes -- two transformer windows, RAFT's two directions (one update-block hipGraph each), fnet | cnet, the two
+    halves of a large feature-propagation group, each next to its sibling on a second stream -- must give the serial schedule's
+    frames bit for bit, every time.  (They did not while the library contained packed fp32 instructions with an `op_sel` half swap:
+    pp_deform_cols next to another stream's MFMA waves dropped the flow's y component in lanes 48..63,
+    profiles/r06_pk_f32_op_sel_erratum.md.)  44 frames of 640x360: 9 windows, 7 of them in one feature-propagation group of 11-frame
+    windows -- no: the group must hold at least 8 windows for its lanes, so neighbor_length 8 (stride 4: 11 windows, 9 of 9 frames)."""
+    from comfyui_propainter_nodes_amd import image_utils, synth
+
+    dev = torch.device("cuda:0")
+    T, H, W = 44, 360, 640
+    image, mask = synth.synthetic_clip(T, H, W)
+    fr, fm, md = image_utils.prepare_frames_and_masks(image_utils.image_to_uint8_frames(image), mask,
+                                                      image_utils.ImageConfig(W, H, 5, 8, (W, H), T))
+    models = pipeline.models_from_state_dicts(weights.synth_state_dicts(0), dev)
+    cfg = pipeline.ProPainterConfig(10, 8, 80, 6, "enable", T, dev, (W, H))
+    lanes = ("PP_RAFT_LANES", "PP_ENC_LANES", "PP_FEATPROP_LANES", "PP_WINDOW_LANES")
+    for k in lanes:
+        monkeypatch.setenv(k, "1")
+    serial = pipeline.run_inpainting(models, fr, fm, md, cfg)
+    for on in lanes + (None,):
+        for k in lanes:
+            monkeypatch.setenv(k, "2" if on in (k, None) else "1")
+        for rep in range(2):
+            got = pipeline.run_inpainting(models, fr, fm, md, cfg)
+            assert torch.equal(got, serial), (on, rep, int((got != serial).sum()))

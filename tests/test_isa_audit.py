@@ -50,3 +50,22 @@ def test_every_barrier_of_an_lds_dma_kernel_retires_its_lds_reads_first():
     r = S.audit_barriers()
     assert r["dma_kernels"] >= 80 and r["barriers"] >= 250, r   # every LDS-DMA kernel family is inside the library
     assert not r["violations"], r["violations"][:10]
+
+
+def test_no_packed_fp32_instruction_swaps_operand_halves():
+    """r06 (profiles/r06_pk_f32_op_sel_erratum.md): on the MI355X `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` -- hipcc's SLP
+    vectoriser emits it for crossed scalar pairs -- returns a wrong low half for lanes 48..63 of a wave while MFMA instructions of
+    another wave share the SIMD: pp_deform_cols computed wrong sample positions whenever a convolution ran next to it on a second
+    stream (tools/diag_deform_debug.py; minimal reproducer without memory traffic: tools/probes/pk_f32_next_to_mfma.hip).  The
+    library is built with -fno-slp-vectorize; this audits the code objects INSIDE the shipped library: no packed fp32 instruction
+    with a set op_sel bit."""
+    import shipped_isa as S
+
+    from comfyui_propainter_nodes_amd import build
+
+    if not S.tools_available():
+        pytest.skip("no llvm-objcopy / llvm-objdump")
+    build.build_hip()
+    r = S.audit_packed_f32_op_sel()
+    assert r["kernels"] >= 150, r["kernels"]
+    assert not r["violations"], r["violations"][:10]
