@@ -37,6 +37,12 @@ __device__ unsigned long long pp_gemm_trace_buf[8192 * 6];
 #else
 #define PP_GT_NOW(v)
 #endif
+// De-phasing experiment (tools/bench_gemm_dephase.py, -DPP_GEMM_DEPHASE; not defined in the product build): work-groups
+// [lo, hi) of a launch sleep `ticks` shader-clock ticks before they start, so that the two work-groups of a CU stop computing
+// and storing in lockstep (profiles/r06_gemm_timeline.md).
+#ifdef PP_GEMM_DEPHASE
+__device__ int pp_gemm_dephase_cfg[4];
+#endif
 
 // PATCH (pp_conv2d_params.flat_taps): the pixel operand is F.unfold(x) of a kh x kw / stride / padding patch grid, gathered on
 // the fly -- row m = output position (n, i, j), column k = (ky, kx, c); a 16-byte piece is 8 channels of ONE tap (C % 8 == 0),
@@ -56,6 +62,16 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
   static_assert((NST - 2) * NL <= 63, "vmcnt is a 6-bit counter");
 
   PP_GT_NOW(gt_start);
+#ifdef PP_GEMM_DEPHASE
+  {
+    const int b = (int)blockIdx.x, mod = pp_gemm_dephase_cfg[3];
+    const bool late = mod > 0 ? (b / mod) % 2 == 1 && b < pp_gemm_dephase_cfg[1] : (b >= pp_gemm_dephase_cfg[0] && b < pp_gemm_dephase_cfg[1]);
+    if (late) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < pp_gemm_dephase_cfg[2]) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+#endif
   T* smem = reinterpret_cast<T*>(PP_DYN_SMEM);
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -287,6 +303,13 @@ int launch_gemm_f16_patch(void* stream, const ConvK& k, int Z, bool out_f16) {
 }
 
 }  // namespace pp
+
+#ifdef PP_GEMM_DEPHASE
+extern "C" int32_t pp_debug_gemm_dephase(int32_t lo, int32_t hi, int32_t ticks, int32_t mod) {
+  const int v[4] = {lo, hi, ticks, mod};
+  return hipMemcpyToSymbol(HIP_SYMBOL(pp::pp_gemm_dephase_cfg), v, sizeof(v)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef PP_GEMM_TRACE
 // (trace build only) copies the work-group timeline of the LAST conv_gemm_f16_kernel launch to the host: 6 x uint64 per work-group
