@@ -247,6 +247,196 @@ __global__ void __launch_bounds__(256) window_attention_generic_kernel(const Att
 
 
 // ----------------------------------------------------------------------------------------
+// fp32 kernel (r06, ABI v11 `exact`): the reference's fp32 attention (sparse_transformer.py:366-393 under fp16 "disable") with
+// NOTHING rounded to f16 -- q, k, v and the probabilities stay fp32, both products run on v_mfma_f32_16x16x4_f32, the
+// exponentials are libm's expf.  Same work decomposition and the same key order as the generic kernel above (block =
+// 128-query tile | frame, head, window; 32-key tiles; online softmax per lane with two xor-shuffles), so the two differ only
+// in operand precision.  An opt-in for comparisons at fp32 level: ~5x the time of the f16-operand kernel.
+//   S^T = K . Q^T : A = K[key = lane & 15][d = 4 s + g], B = q[query = lane & 15][d = 4 s + g], s = 0..31  (g = lane >> 4)
+//                   -> lane holds the scores of query (lane & 15) against keys 4 g + r, r = 0..3, of a 16-key block
+//   O^T += V^T P^T: step r of a 16-key block contracts keys {4 g + r}: A = V[key 4 g + r][d = 16 dt + (lane & 15)],
+//                   B = the lane's own probability r -- the probabilities never leave registers
+// LDS rows have a pitch of 132 floats (132 mod 64 = 4): both fragment reads touch 64 different banks.
+// ----------------------------------------------------------------------------------------
+constexpr int kXP = kHeadDim + 4;
+
+__global__ void __launch_bounds__(256) window_attention_f32_exact_kernel(const AttnK<float> k) {
+  __shared__ __attribute__((aligned(16))) float Ks[32 * kXP];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * kXP];
+
+  const int win = (int)blockIdx.z;
+  const int head = (int)blockIdx.y;
+  const int wi = win / k.nww, wj = win - wi * k.nww;
+  const int r0 = wi * kWinH, c0 = wj * kWinW;
+  const bool masked = k.win_masked[win] != 0;
+  const int per_frame = kWinTok + 148 + k.npool;
+  int nq, nk, qbase, frame = 0;
+  if (masked) {
+    nq = k.t * kWinTok;
+    qbase = (int)blockIdx.x * kQBlock;
+    if (qbase >= nq) return;
+    nk = k.nt * per_frame;
+  } else {
+    frame = (int)blockIdx.x;
+    nq = kWinTok;
+    qbase = 0;
+    nk = kWinTok;
+  }
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int qcol = lane & 15, g = lane >> 4;
+
+  bool qvalid[kQG];
+  int qt[kQG], qy[kQG], qx[kQG];
+  float qf[kQG][32];   // q[d = 4 s + g]
+#pragma unroll
+  for (int qi = 0; qi < kQG; ++qi) {
+    const int ql = qbase + (wave * kQG + qi) * 16 + qcol;
+    qvalid[qi] = ql < nq;
+    const int qc = qvalid[qi] ? ql : 0;
+    qt[qi] = masked ? qc / kWinTok : frame;
+    const int qpos = masked ? qc - qt[qi] * kWinTok : qc;
+    qy[qi] = r0 + qpos / kWinW;
+    qx[qi] = c0 + qpos % kWinW;
+    const float* qptr = k.qkv + ((int64_t)(qt[qi] * k.Hp + qy[qi]) * k.Wp + qx[qi]) * (3 * kDim) + head * kHeadDim;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qf[qi][s] = qptr[4 * s + g];
+  }
+
+  f4 o[kQG][8];
+  float m_run[kQG], l_run[kQG];
+#pragma unroll
+  for (int qi = 0; qi < kQG; ++qi) {
+    m_run[qi] = -1.0e30f;
+    l_run[qi] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[qi][i] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool wave_live = qbase + wave * kQG * 16 < nq;
+
+  const int kr = tid >> 3;           // key row staged by this thread
+  const int dbase = (tid & 7) * 16;  // 16 head-dim values
+  f4 kst[4], vst[4];
+  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+    const int kid = kt + kr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kst[e] = vst[e] = f4{0.f, 0.f, 0.f, 0.f};
+    if (kid < nk) {
+      const float *kp, *vp;
+      int fr, r;
+      if (masked) {
+        const int fi = kid / per_frame;
+        r = kid - fi * per_frame;
+        fr = k.t_ind[fi];
+      } else {
+        fr = frame;
+        r = kid;
+      }
+      if (r < kWinTok + 148) {
+        int y, x;
+        if (r < kWinTok) {
+          y = r0 + r / kWinW;
+          x = c0 + r % kWinW;
+        } else {
+          const int ni = r - kWinTok;
+          y = (r0 + (int)k.nb[2 * ni] + k.Hp) % k.Hp;
+          x = (c0 + (int)k.nb[2 * ni + 1] + k.Wp) % k.Wp;
+        }
+        const float* tokp = k.qkv + ((int64_t)(fr * k.Hp + y) * k.Wp + x) * (3 * kDim) + head * kHeadDim;
+        kp = tokp + kDim;
+        vp = tokp + 2 * kDim;
+      } else {
+        const float* tokp = k.pkv + ((int64_t)fr * k.npool + (r - kWinTok - 148)) * (2 * kDim) + head * kHeadDim;
+        kp = tokp;
+        vp = tokp + kDim;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        kst[e] = *reinterpret_cast<const f4*>(kp + dbase + 4 * e);
+        vst[e] = *reinterpret_cast<const f4*>(vp + dbase + 4 * e);
+      }
+    }
+  };
+  load_tile(0);
+  for (int kt = 0; kt < nk; kt += 32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *reinterpret_cast<f4*>(Ks + kr * kXP + dbase + 4 * e) = kst[e];
+      *reinterpret_cast<f4*>(Vs + kr * kXP + dbase + 4 * e) = vst[e];
+    }
+    __syncthreads();
+    if (kt + 32 < nk) load_tile(kt + 32);
+
+    if (wave_live) {
+      f4 sacc[kQG][2];
+#pragma unroll
+      for (int qi = 0; qi < kQG; ++qi) sacc[qi][0] = sacc[qi][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const float a0 = Ks[qcol * kXP + 4 * s + g];
+        const float a1 = Ks[(16 + qcol) * kXP + 4 * s + g];
+#pragma unroll
+        for (int qi = 0; qi < kQG; ++qi) {
+          sacc[qi][0] = mfma_16x16x4_f32(a0, qf[qi][s], sacc[qi][0]);
+          sacc[qi][1] = mfma_16x16x4_f32(a1, qf[qi][s], sacc[qi][1]);
+        }
+      }
+      float pr[kQG][8], alpha[kQG];
+#pragma unroll
+      for (int qi = 0; qi < kQG; ++qi) {
+        float sc[8];
+        float mt = -1.0e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[r] = (kt + 4 * g + r < nk) ? sacc[qi][0][r] * k.scale : -1.0e30f;
+          sc[4 + r] = (kt + 16 + 4 * g + r < nk) ? sacc[qi][1][r] * k.scale : -1.0e30f;
+          mt = fmaxf(mt, fmaxf(sc[r], sc[4 + r]));
+        }
+        mt = fmaxf(mt, shfl_xor(mt, 16));
+        mt = fmaxf(mt, shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run[qi], mt);
+        alpha[qi] = expf(m_run[qi] - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          pr[qi][i] = expf(sc[i] - m_new);
+          ps += pr[qi][i];
+        }
+        ps += shfl_xor(ps, 16);
+        ps += shfl_xor(ps, 32);
+        l_run[qi] = l_run[qi] * alpha[qi] + ps;
+        m_run[qi] = m_new;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+#pragma unroll
+        for (int qi = 0; qi < kQG; ++qi) o[qi][dt] = o[qi][dt] * alpha[qi];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = Vs[(kb * 16 + 4 * g + r) * kXP + dt * 16 + qcol];
+#pragma unroll
+            for (int qi = 0; qi < kQG; ++qi) o[qi][dt] = mfma_16x16x4_f32(a, pr[qi][kb * 4 + r], o[qi][dt]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qi = 0; qi < kQG; ++qi) {
+    if (!qvalid[qi] || qy[qi] >= k.fh || qx[qi] >= k.fw) continue;
+    const float inv = 1.f / l_run[qi];
+    float* dst = k.out + ((int64_t)(qt[qi] * k.fh + qy[qi]) * k.fw + qx[qi]) * kDim + head * kHeadDim;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f4*>(dst + dt * 16 + 4 * g) = o[qi][dt] * inv;
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------
 // f16 kernel (r03)
 //
 // Work-group = 4 waves; a wave owns 32 queries of one (window, head).  Masked window: the work-group is a 128-query
@@ -699,6 +889,12 @@ static int launch_window_attention_generic(void* stream, const pp_window_attenti
   if (fill_neighbour_table(k.nb) != 148) return pp_fail(PP_ERR_LAUNCH, "pp_window_attention: internal neighbour table error");
   const int nwin = (k.Hp / kWinH) * k.nww;
   dim3 grid((unsigned)k.t, kHeads, (unsigned)nwin);
+  if constexpr (std::is_same<T, float>::value) {
+    if (p->exact) {
+      PP_LAUNCH(window_attention_f32_exact_kernel, grid, dim3(256), 0, stream, k);
+      return pp_check_launch("pp_window_attention");
+    }
+  }
   PP_LAUNCH((window_attention_generic_kernel<T>), grid, dim3(256), 0, stream, k);
   return pp_check_launch("pp_window_attention");
 }
@@ -771,6 +967,8 @@ extern "C" int32_t pp_window_attention(void* stream, const pp_window_attention_p
     return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: null argument");
   if (p->Hp % kWinH || p->Wp % kWinW) return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: grid not padded to 5x9 windows");
   if (p->t < 1 || p->nt < 1 || p->t > 65535) return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: bad t / nt");
+  if (p->exact != 0 && (p->exact != 1 || p->dtype != PP_F32))
+    return pp_fail(PP_ERR_BAD_ARG, "pp_window_attention: exact is 0 or 1, and 1 only with PP_F32 storage");
   if (p->dtype == PP_F16) {
     // the f16 kernel keeps 32-bit element offsets inside a frame and the t_ind table in LDS; beyond those limits the
     // generic kernel (64-bit addressing, no table) serves f16 storage as it did until r02

@@ -54,8 +54,9 @@ class InpaintGeneratorMI355:
     def __init__(self, sd: dict, device, dtype: torch.dtype = F16):
         """`dtype` = storage type of the activations: f16 (the node's fp16 "enable": the reference runs the generator
         `.half()`) or f32 (fp16 "disable").  In f32 the convolutions / linears multiply with the two-term operand split of
-        PP_F32X2 (or on the f32 MFMA instructions under PP_F32_GEMM=exact); the attention core rounds q, k, v and the
-        probabilities to f16 for its MFMAs and keeps scores, statistics, accumulators and outputs in fp32."""
+        PP_F32X2 and the attention core rounds q, k, v and the probabilities to f16 for its MFMAs (scores, statistics,
+        accumulators and outputs in fp32); under PP_F32_GEMM=exact both run on the f32 MFMA instructions with fp32 operands
+        (r06: ops.attention_exact_enabled(), ABI v11) -- the reference's fp32 generator at fp32 rounding level."""
         self.device = torch.device(device)
         self.dt = dtype
         self._geometry_flags: dict = {}   # outpaint geometry -> masked-window flags (window_mask_flags)
@@ -408,7 +409,8 @@ class InpaintGeneratorMI355:
         # static buffer and is consumed by the soft composition right below
         # (`lane`: two windows in flight on two streams -- pipeline.run_inpainting -- replay two INSTANCES of a shape's graph: a
         #  captured sweep owns its static buffers)
-        tok = self._graphs.run(("transformer", h, w, os.environ.get("PP_FC2_UNFOLD", "fused"), lane),
+        tok = self._graphs.run(("transformer", h, w, os.environ.get("PP_FC2_UNFOLD", "fused"), lane,
+                                self.dt == torch.float32 and ops.attention_exact_enabled()),
                                lambda tk, fl: self._transformer(tk, (h, w), fl), tok, flags)
         # soft composition + residual, only for the local frames that are decoded (:443-451)
         emb = torch.empty(lt, fh, fw, 6272, device=dev, dtype=self.dt)

@@ -388,10 +388,12 @@ class ProPainterInpaint:
     """ComfyUI Node for performing inpainting on video frames using ProPainter.
 
     `fp16`: "enable" = f16 storage of flow completion and the generator (the reference's `.half()`), RAFT on f32 tensors;
-    "disable" = fp32 STORAGE of all three networks.  In both modes the matrix products run on the f16 matrix pipe: fp32
-    tensors multiply as two-term f16 splits (PP_F32X2: 22 significant bits per operand, fp32 accumulation; PP_F32_GEMM=exact
-    selects the f32 MFMA instructions) and the attention core rounds q, k, v and the probabilities to f16 -- "disable" is
-    72-78 dB from the reference's fp32 CPU run, not bit-level fp32 arithmetic."""
+    "disable" = fp32 STORAGE of all three networks.  By default the matrix products run on the f16 matrix pipe in both modes: fp32
+    tensors multiply as two-term f16 splits (PP_F32X2: 22 significant bits per operand, fp32 accumulation) and the attention
+    core rounds q, k, v and the probabilities to f16 -- "disable" is then 61-78 dB from the reference's fp32 CPU run.  The
+    environment variable PP_F32_GEMM=exact (read when the models are built) puts every product of "disable" -- convolutions,
+    Linears and, since r06, the attention core -- on the f32 MFMA instructions with fp32 operands: the reference's fp32
+    arithmetic up to summation order, at several times the run time."""
 
     def __init__(self):
         pass

@@ -1028,9 +1028,20 @@ def pool_tokens(x: torch.Tensor, out: torch.Tensor, weight: torch.Tensor, bias: 
     return out
 
 
+def attention_exact_enabled() -> bool:
+    """fp32 storage only: q, k, v and the probabilities stay fp32 (ABI v11 `exact`) when the f32 convolutions are on the f32 MFMA
+    instructions too (PP_F32_GEMM=exact: the whole fp16 "disable" generator at fp32 level), or on its own with PP_ATTN_F32=exact;
+    PP_ATTN_F32=f16 keeps the f16 MFMA operands whatever PP_F32_GEMM says."""
+    mode = os.environ.get("PP_ATTN_F32", "").lower()
+    if mode in ("exact", "f16"):
+        return mode == "exact"
+    return not f32_split_enabled()
+
+
 def window_attention(qkv: torch.Tensor, pkv: torch.Tensor, win_masked: torch.Tensor, t_ind: torch.Tensor,
-                     out: torch.Tensor) -> torch.Tensor:
-    """qkv f16 [t,Hp,Wp,1536], pkv f16 [t,npool,1024], win_masked i32 [nwin], t_ind i32 [nt] -> out f16 [t,fh,fw,512]."""
+                     out: torch.Tensor, exact: bool | None = None) -> torch.Tensor:
+    """qkv f16 [t,Hp,Wp,1536], pkv f16 [t,npool,1024], win_masked i32 [nwin], t_ind i32 [nt] -> out f16 [t,fh,fw,512]
+    (or all three fp32; `exact`: see attention_exact_enabled(), fp32 storage only)."""
     check_device(qkv, pkv, win_masked, t_ind, out)
     t, hp, wp, c3 = qkv.shape
     _, fh, fw, c = out.shape
@@ -1045,6 +1056,9 @@ def window_attention(qkv: torch.Tensor, pkv: torch.Tensor, win_masked: torch.Ten
     if not (qkv.dtype == pkv.dtype == out.dtype):
         raise TypeError("window_attention: qkv, pkv and out must share a dtype")
     P.dtype = dtype_code(qkv.dtype)
+    if exact and qkv.dtype != torch.float32:
+        raise ValueError("window_attention: the exact (fp32-operand) core needs fp32 storage")
+    P.exact = int(qkv.dtype == torch.float32 and (attention_exact_enabled() if exact is None else bool(exact)))
     P.t, P.nt, P.Hp, P.Wp, P.fh, P.fw, P.npool = t, t_ind.numel(), hp, wp, fh, fw, pkv.shape[1]
     P.scale = 1.0 / (128 ** 0.5)
     if CONV_PROFILE is not None and out.is_cuda:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 10
+#define PP_ABI_VERSION 11
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -494,7 +494,10 @@ typedef struct {
   void* out;
   int64_t t, nt, Hp, Wp, fh, fw, npool;
   float scale;
-  int32_t dtype; /* qkv, pkv, out: PP_F16 or PP_F32 (fp32 storage is rounded to f16 for the MFMA operands) */
+  int32_t dtype; /* qkv, pkv, out: PP_F16 or PP_F32 (fp32 storage is rounded to f16 for the MFMA operands unless `exact`) */
+  int32_t exact; /* ABI v11, PP_F32 storage only: 1 = q, k, v and the probabilities stay fp32 and both products run on
+                    v_mfma_f32_16x16x4_f32 with libm's expf -- the reference's fp32 attention (sparse_transformer.py:366-393)
+                    at fp32 rounding level, ~5x the time of the default; 0 = f16 MFMA operands.  Must be 0 for PP_F16. */
 } pp_window_attention_params;
 int32_t pp_window_attention(void* stream, const pp_window_attention_params* p);
 

@@ -271,3 +271,38 @@ def test_window_attention_every_remainder_of_the_tile_loop(backend, fh, fw, tile
     ops.window_attention(qkv.to(dev), pkv.to(dev), flags.to(dev), t_ind.to(dev), out)
     err = (out.float().cpu() - ref).abs().max().item()
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("fh,fw,t", [(10, 18, 4), (15, 27, 7)])
+def test_window_attention_exact_fp32_core(backend, fh, fw, t):
+    """ABI v11 `exact` (fp32 storage): q, k, v and the probabilities stay fp32, both products on v_mfma_f32_16x16x4_f32 -- the
+    reference's fp32 attention (sparse_transformer.py:366-393 under fp16 "disable") at fp32 rounding level.  fp32 inputs that are
+    NOT f16-representable (the default core rounds them: its error on the same data is two orders larger), masked and unmasked
+    windows, partial 128-query blocks ((15, 27, 7): 315 queries), a ragged last key tile, one score spike in a late tile."""
+    dev = backend
+    g = torch.Generator().manual_seed(47)
+    Hp, Wp = math.ceil(fh / 5) * 5, math.ceil(fw / 9) * 9
+    npool = (Hp // 4) * (Wp // 4)
+    qkv = torch.zeros(t, Hp, Wp, 1536)
+    qkv[:, :fh, :fw] = torch.randn(t, fh, fw, 1536, generator=g) * 0.7
+    pkv = torch.randn(t, npool, 1024, generator=g) * 0.7
+    nwin = (Hp // 5) * (Wp // 9)
+    flags = torch.zeros(nwin, dtype=torch.int32)
+    flags[0] = flags[nwin - 1] = 1
+    t_ind = torch.arange(1, t, 2, dtype=torch.int32)
+    q = qkv[2, 1, 3, :128].clone()
+    pkv[int(t_ind[-1]), npool - 1, :128] = 25.0 * q / q.norm()       # a late pooled key that dominates one query's row
+    ref = _attention_reference(qkv, pkv, flags, t_ind, fh, fw)
+    scale = max(1.0, ref.abs().max().item())
+    out = torch.empty(t, fh, fw, 512, dtype=torch.float32, device=dev)
+    ops.window_attention(qkv.to(dev), pkv.to(dev), flags.to(dev), t_ind.to(dev), out, exact=True)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 1e-5 * scale, err
+    rounded = torch.empty_like(out)
+    ops.window_attention(qkv.to(dev), pkv.to(dev), flags.to(dev), t_ind.to(dev), rounded, exact=False)
+    err16 = (rounded.cpu() - ref).abs().max().item()
+    assert 20 * err < err16 < 4e-3 * scale, (err, err16)             # the flag selects a different, much tighter core
+    # fp16 storage has no exact form
+    with pytest.raises(Exception):
+        ops.window_attention(qkv.half().to(dev), pkv.half().to(dev), flags.to(dev), t_ind.to(dev),
+                             torch.empty(t, fh, fw, 512, dtype=torch.float16, device=dev), exact=True)
