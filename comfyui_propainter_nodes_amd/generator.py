@@ -189,12 +189,16 @@ class InpaintGeneratorMI355:
         return st
 
     # ------------------------------------------------------------------------------------------------
-    def propagate_windows(self, st: ClipState, windows: list[list[int]]) -> list[torch.Tensor]:
+    def propagate_windows(self, st: ClipState, windows: list[list[int]], ready: list | None = None) -> list[torch.Tensor]:
         """BidirectionalPropagation(learnable=True) (propainter.py:118-231) for the local frames of EVERY
         window of the clip.  Windows are independent, so all windows with the same number of local
         frames advance through the recurrence together as one batch: step i of the pass is a batch of
         `nw` images (one per window) instead of `nw` launches of 1 image.  Returns, per window, the
-        propagated local features f16 [l_t,h,w,128]."""
+        propagated local features f16 [l_t,h,w,128].
+        `ready` (r06, PP_FEATPROP_PIPE): a list the caller passes to take part in the schedule -- entry wi is None when
+        window wi's tensor is ordered by the launch stream, or an event its consumer must wait for: the second half of a
+        large group then runs on the side stream BEHIND the first half (not next to it), i.e. next to the transformer of the
+        first windows, and nobody joins the side stream here."""
         result: list[torch.Tensor | None] = [None] * len(windows)
         groups: dict[int, list[int]] = {}
         for wi, nb in enumerate(windows):
@@ -208,6 +212,8 @@ class InpaintGeneratorMI355:
         # tests/test_e2e.py::test_stream_lanes_are_bit_identical_and_reproducible runs every lane against the serial schedule.)
         two = (os.environ.get("PP_FEATPROP_LANES", "2") != "1" and st.enc.is_cuda and not torch.cuda.is_current_stream_capturing()
                and ops.CONV_PROFILE is None)
+        if ready is not None:
+            ready[:] = [None] * len(windows)
         for lt, wis in groups.items():
             if two and len(wis) >= 8:
                 dev = st.enc.device
@@ -215,6 +221,18 @@ class InpaintGeneratorMI355:
                 if self._side is None:
                     self._side = torch.cuda.Stream(dev)
                 side, half = self._side, (len(wis) + 1) // 2
+                if ready is not None:
+                    out_a = self._feature_propagation_batch(st, [windows[wi][0] for wi in wis[:half]], lt)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        out_b = self._feature_propagation_batch(st, [windows[wi][0] for wi in wis[half:]], lt)
+                        done = torch.cuda.Event()
+                        done.record(side)
+                    for j, wi in enumerate(wis):
+                        result[wi] = out_a[:, j] if j < half else out_b[:, j - half]
+                        if j >= half:
+                            ready[wi] = done
+                    continue
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     out_b = self._feature_propagation_batch(st, [windows[wi][0] for wi in wis[half:]], lt)

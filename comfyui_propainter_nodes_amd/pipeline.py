@@ -308,7 +308,12 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
         trace.update(gt_flows=gt, pred_flows=pred, updated_frames=updated, updated_masks=upd, pred_imgs=[])
     schedule, spans, table = device_schedule(config)
     gen.reference_tokens(st, sorted({r for _, refs in schedule for r in refs}))   # one embedding per reference frame of the clip
-    props = gen.propagate_windows(st, [nb for nb, _ in schedule])
+    # r06 (PP_FEATPROP_PIPE=1): the second half of the large feature-propagation group runs on the generator's side stream next to
+    # the transformer of the first windows instead of next to the first half; a window then waits for its own tensor's event
+    pipe = (os.environ.get("PP_FEATPROP_PIPE", "0") == "1" and fr_u8.is_cuda and trace is None and ops.CONV_PROFILE is None
+            and not torch.cuda.is_current_stream_capturing())
+    prop_ready: list = [None] * len(schedule)
+    props = gen.propagate_windows(st, [nb for nb, _ in schedule], ready=prop_ready if pipe else None)
     mark("feature_propagation(all windows batched)")
     finals = final_ranges(schedule, T) if sink is not None else None
     # r06: windows are independent until the order-dependent uint8 compose, so `lanes` consecutive windows run next to each other
@@ -340,8 +345,12 @@ def run_inpainting(models: Models, frames_u8, flow_masks_u8, masks_dilated_u8, c
             side.wait_stream(main)                   # props / clip state / the previous group's buffers are ready
             with torch.cuda.stream(side):
                 nb, refs = schedule[wi]
+                if prop_ready[wi] is not None:
+                    side.wait_event(prop_ready[wi])
                 outs[wi] = gen.forward_window(st, nb, refs, local_prop=props[wi], lane=k)
         nb, refs = schedule[w0]
+        if prop_ready[w0] is not None:
+            torch.cuda.current_stream(dev).wait_event(prop_ready[w0])
         outs[w0] = gen.forward_window(st, nb, refs, local_prop=props[w0])
         for k, wi in enumerate(group):
             if k > 0:

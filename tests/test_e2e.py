@@ -145,6 +145,11 @@ def test_stream_lanes_are_bit_identical_and_reproducible(hip_lib, monkeypatch):
         for rep in range(2):
             got = pipeline.run_inpainting(models, fr, fm, md, cfg)
             assert torch.equal(got, serial), (on, rep, int((got != serial).sum()))
+    # the second half of the feature-propagation group behind the first one, next to the first windows' transformer (PP_FEATPROP_PIPE)
+    monkeypatch.setenv("PP_FEATPROP_PIPE", "1")
+    for rep in range(2):
+        got = pipeline.run_inpainting(models, fr, fm, md, cfg)
+        assert torch.equal(got, serial), ("pipe", rep, int((got != serial).sum()))
 
 
 @pytest.mark.gpu
