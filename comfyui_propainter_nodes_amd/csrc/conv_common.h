@@ -58,6 +58,7 @@ struct ConvK {
   int flat_taps;            // weights = one (ky, kx, c)-ordered row per output channel; conv_gemm_f16.hip gathers the patches
   float acc_scale;          // PP_F32X2: 1 / (power-of-two scale of the packed weights); 1 otherwise
   int epi_lds;              // 1 (default): LDS-transposed epilogue (epilogue_quads_lds); 0 (PP_CONV_EPI=direct): quads stored as the MFMA leaves them
+  int epi_oct;              // 1 (default): the GEMM kernel's f16 outputs as 16-byte stores of paired quads (epilogue_octs_fast); 0 (PP_CONV_EPI_OCT=0): 8-byte quads
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float param) {
@@ -370,6 +371,111 @@ __device__ __forceinline__ void epilogue_quads(const ConvK& p, const EpiCtx<OT>&
   } else {
     epilogue_quads_general<OT, NA, NB>(p, e, row, chan, val);
   }
+}
+
+// ---- paired quads (r06, f16 outputs).  Two channel-adjacent 16 x 16 tiles of a wave leave lane (g, j) -- g = lane >> 4 -- the
+// channels 4g..4g+3 of BOTH tiles for pixel j: 8-byte stores, 32 bytes per pixel and instruction.  Four v_permlane16_swap (rows 1 <-> 0
+// and 3 <-> 2 between the two quads) give every lane 8 CONSECUTIVE channels of one tile instead -- rows 0 / 2: channels 0-7 / 8-15 of
+// the first tile, rows 1 / 3: of the second -- so a wave stores 16 bytes per lane, 64 bytes per pixel and instruction, in half the
+// store (and residual / pre-add load) instructions.  Pure data movement in front of store_quad_fast()'s arithmetic: the same bits.
+template <typename OT>
+__device__ __forceinline__ bool epi_oct_ok(const ConvK& p, const EpiCtx<OT>& e) {
+  if constexpr (sizeof(OT) != 2) {
+    return false;
+  } else {
+    bool ok = epi_fast_ok<OT>(p, e);
+    ok = ok && (p.Cout & 7) == 0 && (p.act_split & 7) == 0 && (p.out_ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(e.out) & 15) == 0;
+    ok = ok && (!e.pre || ((p.pre_add_ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(e.pre) & 15) == 0));
+    if (p.epi != PP_EPI_NONE) {
+      ok = ok && (p.epi_from & 7) == 0 && (p.aux1_ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(e.aux1) & 15) == 0;
+      if (p.epi == PP_EPI_GRU) ok = ok && (p.aux2_ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(e.aux2) & 15) == 0;
+    }
+    return ok;
+  }
+}
+
+__device__ __forceinline__ void load_oct_vec(const half_t* src, f4& lo, f4& hi) {
+  const h8 t = *reinterpret_cast<const h8*>(src);
+  lo = f4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+  hi = f4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
+}
+
+// store_quad_fast() on the two quads of 8 consecutive channels c..c+7 of pixel m (same operations in the same order per value)
+__device__ __forceinline__ void store_oct_fast(const ConvK& p, const EpiCtx<half_t>& e, f4 v0, f4 v1, int64_t m, int c) {
+  if (e.bias) {
+    v0 += *reinterpret_cast<const f4*>(e.bias + c);
+    v1 += *reinterpret_cast<const f4*>(e.bias + c + 4);
+  }
+  if (e.pre) {
+    f4 a, b;
+    load_oct_vec(e.pre + m * p.pre_add_ldc + c, a, b);
+    v0 += a;
+    v1 += b;
+  }
+  if (p.act_split > 0 && c >= p.act_split) {
+    v0 = apply_act4(v0, p.act2, p.act_param);
+    v1 = apply_act4(v1, p.act2, p.act_param);
+  } else {
+    v0 = apply_act4(v0, p.act, p.act_param);
+    v1 = apply_act4(v1, p.act, p.act_param);
+    if (p.out_scale != 0.f) {
+      v0 *= p.out_scale;
+      v1 *= p.out_scale;
+    }
+  }
+  if (p.epi != PP_EPI_NONE && c >= p.epi_from) {
+    f4 a0, a1;
+    load_oct_vec(e.aux1 + m * p.aux1_ldc + (c - p.epi_from), a0, a1);
+    if (p.epi == PP_EPI_MUL_AUX1) {
+      v0 *= a0;
+      v1 *= a1;
+    } else if (p.epi == PP_EPI_ADD_AUX1) {
+      v0 += a0;
+      v1 += a1;
+    } else if (p.epi == PP_EPI_ADD_AUX1_RELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s0 = v0[r] + a0[r], s1 = v1[r] + a1[r];
+        v0[r] = s0 > 0.f ? s0 : 0.f;
+        v1[r] = s1 > 0.f ? s1 : 0.f;
+      }
+    } else if (p.epi == PP_EPI_GRU) {
+      f4 h0, h1;
+      load_oct_vec(e.aux2 + m * p.aux2_ldc + (c - p.epi_from), h0, h1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v0[r] = (1.f - a0[r]) * h0[r] + a0[r] * v0[r];
+        v1[r] = (1.f - a1[r]) * h1[r] + a1[r] * v1[r];
+      }
+    }
+  }
+  const h8 o = {sat_half(v0[0]), sat_half(v0[1]), sat_half(v0[2]), sat_half(v0[3]),
+                sat_half(v1[0]), sat_half(v1[1]), sat_half(v1[2]), sat_half(v1[3])};
+  *reinterpret_cast<h8*>(e.out + m * p.out_ldc + c) = o;
+}
+
+// wave tile of NA x NB quads, NA even; chan0 = the wave tile's first channel; g = lane >> 4
+template <int NA, int NB, typename RowFn, typename ValFn>
+__device__ __forceinline__ void epilogue_octs_fast(const ConvK& p, const EpiCtx<half_t>& e, int chan0, int g, RowFn row, ValFn val) {
+  static_assert(NA % 2 == 0, "quad rows are paired");
+  static_for<NB>([&](auto bi) {
+    int64_t m;
+    bool ok;
+    row(bi, m, ok);
+    static_for<NA / 2>([&](auto a2) {
+      constexpr int A = 2 * decltype(a2)::value;
+      f4 v0 = val(std::integral_constant<int, A>{}, bi), v1 = val(std::integral_constant<int, A + 1>{}, bi);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // every lane takes part, whatever `ok`
+        float a = v0[r], b = v1[r];
+        swap_rows16(a, b);
+        v0[r] = a;
+        v1[r] = b;
+      }
+      const int c = chan0 + (A + (g & 1)) * 16 + (g >> 1) * 8;
+      if (ok && c < p.Cout) store_oct_fast(p, e, v0, v1, m, c);
+    });
+  });
 }
 
 // ---- LDS-transposed epilogue (r05).  The MFMA leaves a lane 4 consecutive channels of ONE pixel per 16 x 16 tile, neighbouring

@@ -218,6 +218,20 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
   // (r05: the LDS-transposed epilogue LOSES on these short-reduction GEMMs -- fc1 631 -> 460, qkv 588 -> 459 TF/s: four exposed LDS
   //  round trips per wave against a loop of ~8 000 cycles -- so they keep the direct quads: EPI_FITS = false)
   constexpr bool EPI_FITS = false;
+  // r06: f16 outputs leave the wave as 16-byte stores of 8 consecutive channels (conv_common.h: epilogue_octs_fast) whenever every
+  // tensor of the launch allows it -- all of the transformer's Linears do
+  if constexpr (sizeof(OT) == 2 && TC % 2 == 0) {
+    if (p.epi_oct && epi_oct_ok<OT>(p, e)) {
+      epilogue_octs_fast<TC, TP>(
+          p, e, c_base + wc * TC * 16, fgrp,
+          [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
+            m = p_base + wp * TP * 16 + decltype(bi)::value * 16 + frow;
+            ok = m < p.M;
+          },
+          [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
+      return;
+    }
+  }
   epilogue_any<OT, TC, TP, EPI_FITS>(
       p, e, reinterpret_cast<unsigned char*>(smem), wave, lane, c_base + wc * TC * 16,
       [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {

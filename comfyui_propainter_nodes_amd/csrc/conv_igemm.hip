@@ -84,6 +84,7 @@ int convk_from_params(const pp_conv2d_params* p, ConvK* kp, const char* who, boo
   k.weight_f32 = reinterpret_cast<const float*>(p->weight_f32);
   k.tile_order = options().conv_order;
   k.epi_lds = options().epi_lds;
+  k.epi_oct = options().epi_oct;
   k.acc_scale = (p->dtype == PP_F32X2 && p->acc_scale != 0.f) ? p->acc_scale : 1.f;
   if (p->pre_add && p->Z != 1) return fail2(PP_ERR_UNSUPPORTED, who, "pre_add with Z > 1");
   return PP_OK;

@@ -143,6 +143,12 @@ __device__ __forceinline__ void pp_wave_lds_fence() {
 }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
+// v_permlane16_swap: rows are 16 lanes; row 1 of `a` <-> row 0 of `b`, row 3 of `a` <-> row 2 of `b` (one VALU instruction, gfx950)
+__device__ __forceinline__ void swap_rows16(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  a = __builtin_bit_cast(float, (unsigned)r[0]);
+  b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #else
 inline void pp_wave_lds_fence() { pp_emu::wave_sync(); }
@@ -249,6 +255,22 @@ inline float shfl_idx(float v, int src) {
   const float r = s[(src & 63) * 16];
   pp_emu::wave_sync();
   return r;
+}
+inline void swap_rows16(float& a, float& b) {
+  struct Slot {
+    float a, b;
+    unsigned char pad[56];
+  };
+  Slot* s = reinterpret_cast<Slot*>(pp_emu::wave_scratch());
+  const int l = pp_emu::cur->lane;
+  s[l].a = a;
+  s[l].b = b;
+  pp_emu::wave_sync();
+  const bool odd = (l >> 4) & 1;
+  const float na = odd ? s[l - 16].b : a, nb = odd ? b : s[l + 16].a;
+  pp_emu::wave_sync();
+  a = na;
+  b = nb;
 }
 inline int lane_id() { return pp_emu::cur->lane; }
 #endif

@@ -22,6 +22,8 @@
 //   PP_CONV_TRACE    (set)       print which convolution kernel family ran (debugging aid)
 //   PP_CONV_EPI      direct      convolution epilogues store their quads as the MFMA leaves them (r01-r04) instead of transposing them
 //                                through LDS into whole-cache-line rows (r05 default; bit-identical)
+//   PP_CONV_EPI_OCT  0           the GEMM kernel stores its f16 outputs as 8-byte quads (r01-r05) instead of pairing channel-adjacent quads
+//                                into 16-byte stores with v_permlane16_swap (r06 default; bit-identical)
 //   PP_DEFORM_XCD    0           pp_deform_cols / pp_deform_conv walk their pixel blocks in launch order instead of XCD-contiguous order
 #pragma once
 
@@ -40,6 +42,7 @@ struct Options {
   int gemm;        // 0 off, 1 auto, 2 force
   int gemm_cfg;    // 0 auto, 1..5 pinned
   int epi_lds;     // 1 (default): LDS-transposed epilogue; 0: direct quads
+  int epi_oct;     // 1 (default): GEMM kernel, f16 outputs: paired quads, 16-byte stores (r06); 0: 8-byte quads
   int deform_xcd;  // 1 (default): the deformable-sampling kernels walk their pixel blocks in XCD-contiguous order
 };
 const Options& options();
