@@ -220,8 +220,10 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
   constexpr bool EPI_FITS = false;
   // r06: f16 outputs leave the wave as 16-byte stores of 8 consecutive channels (conv_common.h: epilogue_octs_fast) whenever every
   // tensor of the launch allows it -- all of the transformer's Linears do
+  bool stored = false;
   if constexpr (sizeof(OT) == 2 && TC % 2 == 0) {
     if (p.epi_oct && epi_oct_ok<OT>(p, e)) {
+      stored = true;
       epilogue_octs_fast<TC, TP>(
           p, e, c_base + wc * TC * 16, fgrp,
           [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
@@ -229,10 +231,9 @@ __global__ void __launch_bounds__(WC * WP * 64) conv_gemm_f16_kernel(const ConvK
             ok = m < p.M;
           },
           [&](auto ai, auto bi) PP_INLINE_LAMBDA { return acc[decltype(ai)::value][decltype(bi)::value]; });
-      return;
     }
   }
-  epilogue_any<OT, TC, TP, EPI_FITS>(
+  if (!stored) epilogue_any<OT, TC, TP, EPI_FITS>(
       p, e, reinterpret_cast<unsigned char*>(smem), wave, lane, c_base + wc * TC * 16,
       [&](auto bi, int64_t& m, bool& ok) PP_INLINE_LAMBDA {
         m = p_base + wp * TP * 16 + decltype(bi)::value * 16 + frow;
