@@ -103,6 +103,8 @@ static void load_options() {
   if (const char* e = getenv("PP_CONV_EPI")) o.epi_lds = e[0] != 'd';
   o.epi_oct = 1;
   if (const char* e = getenv("PP_CONV_EPI_OCT")) o.epi_oct = e[0] != '0';
+  o.upsample_b4 = 1;
+  if (const char* e = getenv("PP_UPSAMPLE_B4")) o.upsample_b4 = e[0] != '0';
   o.deform_xcd = 1;
   if (const char* e = getenv("PP_DEFORM_XCD")) o.deform_xcd = e[0] != '0';
   std::lock_guard<std::mutex> lock(g_options_mutex);

@@ -176,6 +176,74 @@ __global__ void __launch_bounds__(256) upsample2x_h8_kernel(const T* __restrict_
   st8(out + opix * out_ldc + pc * 8, o);
 }
 
+// r06: one thread per INPUT pixel x 8-channel piece computes the 2 x 2 output block (2i, 2i+1) x (2j, 2j+1).  With align_corners the
+// even output row 2i lies between input rows i-1 and i and the odd one between i and i+1 (columns alike), so the block reads a 3 x 3
+// neighbourhood: 9 loads per 4 stores instead of 16 (2.2-2.6 TB/s -> see tools/bench_upsample.py).  Every output keeps the per-pixel
+// arithmetic of the kernel above -- its own y0 / y1 / ly from the same float expressions -- and only where a row / column index it
+// asks for is one already loaded for its neighbour is the load shared: the same bits.
+template <typename T>
+__global__ void __launch_bounds__(256) upsample2x_b4_kernel(const T* __restrict__ in, int in_ldc,
+                                                            T* __restrict__ out, int out_ldc, int H, int W,
+                                                            int C, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over N*H*W*(C/8)
+  if (idx >= total) return;
+  const int pieces = C / 8;
+  const int pc = (int)(idx % pieces);
+  const int64_t ipix = idx / pieces;
+  const int j = (int)(ipix % W);
+  const int64_t t = ipix / W;
+  const int i = (int)(t % H);
+  const int64_t n = t / H;
+  const int Wo = 2 * W, Ho = 2 * H;
+  const float sy = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  int y0[2], y1[2], x0[2], x1[2];
+  float ly[2], lx[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float fy = sy * (float)(2 * i + a), fx = sx * (float)(2 * j + a);
+    y0[a] = (int)fy;
+    x0[a] = (int)fx;
+    y1[a] = y0[a] + (y0[a] < H - 1 ? 1 : 0);
+    x1[a] = x0[a] + (x0[a] < W - 1 ? 1 : 0);
+    ly[a] = fy - (float)y0[a];
+    lx[a] = fx - (float)x0[a];
+  }
+  // rows r = {y0[0], y1[0] (== y0[1] in exact arithmetic), y1[1]}; the rare lanes where float rounding says otherwise reload
+  const int ry[3] = {y0[0], y1[0], y1[1]}, rx[3] = {x0[0], x1[0], x1[1]};
+  const T* base = in + n * (int64_t)H * W * in_ldc + pc * 8;
+  float v[3][3][8];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) ld8(base + ((int64_t)ry[a] * W + rx[b]) * in_ldc, v[a][b]);
+  const bool shared_y = y0[1] == y1[0], shared_x = x0[1] == x1[0];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float o[8];
+      if (shared_y && shared_x) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = (1.f - ly[a]) * ((1.f - lx[b]) * v[a][b][e] + lx[b] * v[a][b + 1][e]) +
+                 ly[a] * ((1.f - lx[b]) * v[a + 1][b][e] + lx[b] * v[a + 1][b + 1][e]);
+      } else {   // (never taken for the sizes in use: kept so that the result cannot depend on a rounding of sy * yo)
+        float v00[8], v01[8], v10[8], v11[8];
+        ld8(base + ((int64_t)y0[a] * W + x0[b]) * in_ldc, v00);
+        ld8(base + ((int64_t)y0[a] * W + x1[b]) * in_ldc, v01);
+        ld8(base + ((int64_t)y1[a] * W + x0[b]) * in_ldc, v10);
+        ld8(base + ((int64_t)y1[a] * W + x1[b]) * in_ldc, v11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = (1.f - ly[a]) * ((1.f - lx[b]) * v00[e] + lx[b] * v01[e]) + ly[a] * ((1.f - lx[b]) * v10[e] + lx[b] * v11[e]);
+      }
+      const int64_t opix = (n * Ho + (2 * i + a)) * Wo + (2 * j + b);
+      st8(out + opix * out_ldc + pc * 8, o);
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // flow-completion input / output passes
 // ----------------------------------------------------------------------------------------
@@ -255,7 +323,16 @@ extern "C" int32_t pp_upsample2x(void* stream, const pp_upsample2x_params* p) {
   if (total <= 0) return pp_fail(PP_ERR_BAD_ARG, "pp_upsample2x: empty problem");
   const bool vec8 = (p->C % 8) == 0 && (p->in_ldc % 8) == 0 && (p->out_ldc % 8) == 0 &&
                     ((reinterpret_cast<uintptr_t>(p->in) | reinterpret_cast<uintptr_t>(p->out)) & 15) == 0;
-  if (p->dtype == PP_F16 && vec8) {
+  const bool blocks4 = options().upsample_b4 != 0;   // (PP_UPSAMPLE_B4=0: one thread per output pixel, r01-r05)
+  if (p->dtype == PP_F16 && vec8 && blocks4) {
+    const int64_t tv = total / 32;
+    PP_LAUNCH((upsample2x_b4_kernel<half_t>), dim3(nblk(tv)), dim3(256), 0, stream, (const half_t*)p->in, (int)p->in_ldc,
+              (half_t*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, tv);
+  } else if (p->dtype == PP_F32 && vec8 && blocks4) {
+    const int64_t tv = total / 32;
+    PP_LAUNCH((upsample2x_b4_kernel<float>), dim3(nblk(tv)), dim3(256), 0, stream, (const float*)p->in, (int)p->in_ldc,
+              (float*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, tv);
+  } else if (p->dtype == PP_F16 && vec8) {
     const int64_t tv = total / 8;
     PP_LAUNCH((upsample2x_h8_kernel<half_t>), dim3(nblk(tv)), dim3(256), 0, stream, (const half_t*)p->in, (int)p->in_ldc,
               (half_t*)p->out, (int)p->out_ldc, (int)p->H, (int)p->W, (int)p->C, tv);

@@ -83,16 +83,26 @@ def test_fused_deform_conv_matches_the_two_kernel_form(backend, pp_knobs, xcd):
         assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
 
 
-def test_upsample2x_align_corners(backend):
+def test_upsample2x_align_corners(backend, pp_knobs):
+    """Against torch's bilinear interpolation; r06: the 2 x 2-block kernel (one thread per input pixel: 9 loads per 4 stores) must
+    equal the per-output-pixel kernel BIT FOR BIT -- odd sizes, a single row / column (H - 1 = 0: every output row reads row 0), the
+    decoder's aspect, and 4 channels (the per-element kernel: no 8-channel pieces)."""
     dev = backend
     g = torch.Generator().manual_seed(12)
-    x = torch.randn(2, 7, 9, 16, generator=g)
-    for dt, tol in ((torch.float32, 1e-5), (torch.float16, 2e-3)):
-        out = torch.empty(2, 14, 18, 16, device=dev, dtype=dt)
-        ops.upsample2x(x.to(dt).to(dev), out)
-        ref = F.interpolate(x.to(dt).float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear",
-                            align_corners=True).permute(0, 2, 3, 1)
-        assert (out.float().cpu() - ref).abs().max().item() < tol * ref.abs().max().item()
+    for shape in ((2, 7, 9, 16), (1, 1, 5, 8), (1, 6, 1, 24), (1, 45, 80, 8), (1, 3, 4, 4)):
+        x = torch.randn(*shape, generator=g)
+        n, h, w, c = shape
+        for dt, tol in ((torch.float32, 1e-5), (torch.float16, 2e-3)):
+            outs = []
+            for b4 in ("1", "0"):
+                pp_knobs(PP_UPSAMPLE_B4=b4)
+                out = torch.full((n, 2 * h, 2 * w, c), float("nan"), device=dev, dtype=dt)
+                ops.upsample2x(x.to(dt).to(dev), out)
+                outs.append(out.cpu())
+            assert torch.equal(outs[0], outs[1]), shape
+            ref = F.interpolate(x.to(dt).float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear",
+                                align_corners=True).permute(0, 2, 3, 1)
+            assert (outs[0].float() - ref).abs().max().item() < tol * max(1e-6, ref.abs().max().item())
 
 
 def test_rfc_prep_and_combine(backend):
