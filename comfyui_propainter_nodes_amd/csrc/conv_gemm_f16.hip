@@ -278,6 +278,7 @@ static int launch_gemm_t(void* stream, const ConvK& k, int cfg) {
   //   4: 128 x 128, 4 waves, 1 chunk  per barrier, 4 stages ( 64 KB)                          388 / 376 / 444 / 569
   //   5: 256 x 128, 8 waves, 1 chunk  per barrier, 3 stages ( 72 KB: two per CU)              568 / 513 / 651 / 711
   //   6: 128 x 256, 8 waves, 1 chunk  per barrier, 3 stages ( 72 KB)
+  //   7: 128 x 128, 4 waves, 1 chunk  per barrier, 3 stages ( 48 KB: three per CU)   r06, with the paired-quad stores: see below
   // Fewer barriers per MFMA (1-3) do not pay for halving the resident waves: 4 waves per SIMD is what hides the copies.
   if (cfg == 0) cfg = (k.Cout + 255) / 256 * 256 - k.Cout <= k.Cout / 8 ? 5 : 6;
   if (options().trace) fprintf(stderr, "pp_conv2d: GEMM kernel cfg %d, M %lld, K %d, Cout %d\n", cfg, (long long)k.M, k.in_C[0], k.Cout);
@@ -287,6 +288,7 @@ static int launch_gemm_t(void* stream, const ConvK& k, int cfg) {
     case 3: return launch_gemm_cfg<OT, 2, 4, 4, 4, 2, 3>(stream, k);
     case 4: return launch_gemm_cfg<OT, 2, 2, 4, 4, 1, 4>(stream, k);
     case 6: return launch_gemm_cfg<OT, 2, 4, 4, 4, 1, 3>(stream, k);
+    case 7: return launch_gemm_cfg<OT, 2, 2, 4, 4, 1, 3>(stream, k);   // r06: 128 x 128, 4 waves, 3 stages (48 KB: three per CU)
     default: return launch_gemm_cfg<OT, 4, 2, 4, 4, 1, 3>(stream, k);
   }
 }
