@@ -278,7 +278,9 @@ static int launch_gemm_t(void* stream, const ConvK& k, int cfg) {
   //   4: 128 x 128, 4 waves, 1 chunk  per barrier, 4 stages ( 64 KB)                          388 / 376 / 444 / 569
   //   5: 256 x 128, 8 waves, 1 chunk  per barrier, 3 stages ( 72 KB: two per CU)              568 / 513 / 651 / 711
   //   6: 128 x 256, 8 waves, 1 chunk  per barrier, 3 stages ( 72 KB)
-  //   7: 128 x 128, 4 waves, 1 chunk  per barrier, 3 stages ( 48 KB: three per CU)   r06, with the paired-quad stores: see below
+  //   7: 128 x 128, 4 waves, 1 chunk  per barrier, 3 stages ( 48 KB: three per CU)   r06, paired-quad stores: 437-488 / 365-374 / 465-491
+  //      against 613-682 / 475-499 / 626-689 for 5 on the same box (tools/bench_gemm_cfg.py): three independent phases per CU do not
+  //      make up for twice the operand copies per MFMA
   // Fewer barriers per MFMA (1-3) do not pay for halving the resident waves: 4 waves per SIMD is what hides the copies.
   if (cfg == 0) cfg = (k.Cout + 255) / 256 * 256 - k.Cout <= k.Cout / 8 ? 5 : 6;
   if (options().trace) fprintf(stderr, "pp_conv2d: GEMM kernel cfg %d, M %lld, K %d, Cout %d\n", cfg, (long long)k.M, k.in_C[0], k.Cout);
