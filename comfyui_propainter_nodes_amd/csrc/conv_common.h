@@ -58,6 +58,7 @@ struct ConvK {
   int flat_taps;            // weights = one (ky, kx, c)-ordered row per output channel; conv_gemm_f16.hip gathers the patches
   float acc_scale;          // PP_F32X2: 1 / (power-of-two scale of the packed weights); 1 otherwise
   int epi_lds;              // 1 (default): LDS-transposed epilogue (epilogue_quads_lds); 0 (PP_CONV_EPI=direct): quads stored as the MFMA leaves them
+  int many_images;          // pp_conv2d_params.many_images (ABI v12): never the small-image split-K kernel
   int epi_oct;              // 1 (default): the GEMM kernel's f16 outputs as 16-byte stores of paired quads (epilogue_octs_fast); 0 (PP_CONV_EPI_OCT=0): 8-byte quads
 };
 

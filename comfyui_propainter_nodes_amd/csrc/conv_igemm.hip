@@ -85,6 +85,7 @@ int convk_from_params(const pp_conv2d_params* p, ConvK* kp, const char* who, boo
   k.tile_order = options().conv_order;
   k.epi_lds = options().epi_lds;
   k.epi_oct = options().epi_oct;
+  k.many_images = p->many_images != 0;
   k.acc_scale = (p->dtype == PP_F32X2 && p->acc_scale != 0.f) ? p->acc_scale : 1.f;
   if (p->pre_add && p->Z != 1) return fail2(PP_ERR_UNSUPPORTED, who, "pre_add with Z > 1");
   return PP_OK;

@@ -264,6 +264,7 @@ int launch_ksplit_f16(void* stream, const ConvK& k, int Z, bool out_f16) {
   const int mode = options().ksplit;
   if (mode == 0 || k.nchunks < kKS) return 1;
   if (mode != 2) {
+    if (k.many_images) return 1;   // (ABI v12: a layer that always sees a whole sub-video's images -- the halo / flat tiles fill the chip)
     const int64_t img_blocks32 = (((int64_t)k.Ho * k.Wo + 31) / 32) * ((k.Cout + 127) / 128);
     // an image of at most ~160 32-pixel tiles (45x80 of flow completion: 113) and a reduction worth splitting
     // (>= 8 chunks per group)

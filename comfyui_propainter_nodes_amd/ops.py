@@ -261,6 +261,7 @@ class ConvSpec:
     cin_valid: int = 0            # real (unpadded) input channels per group, for FLOP accounting
     split: bool = False           # f32 tensors on the f16 matrix pipe (PP_F32X2 weight packing)
     acc_scale: float = 0.0        # PP_F32X2: 1 / (the power-of-two scale inside the packed weights); 0 = 1
+    many_images: bool = False     # ABI v12: this layer always runs on a batch of many images (never the small-image split-K kernel)
     weight_f32: torch.Tensor | None = None  # Cout <= 4 only: fp32 [tap*chunk][Cout padded to 2 / 4][32] table (conv_direct.hip)
     geometry_key: tuple | None = None       # (conv2d's parameter-block cache: the fields above that a block depends on, built once)
 
@@ -280,7 +281,7 @@ class ConvSpec:
 
 def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, *, stride=1, padding=0,
                    dilation=1, groups=1, seg_channels=None, seg_valid=None, pad_mode="zeros",
-                   split: bool = False) -> ConvSpec:
+                   split: bool = False, many_images: bool = False) -> ConvSpec:
     def pair(v):
         return (v, v) if isinstance(v, int) else tuple(v)
 
@@ -305,7 +306,7 @@ def make_conv_spec(w: torch.Tensor, b: torch.Tensor | None, dtype: torch.dtype, 
         acc_scale = 0.0
     bias = b.detach().float().contiguous() if b is not None else None
     return ConvSpec(packed, bias, list(seg_channels), cout // groups, kh, kw, sh, sw, ph, pw, dh, dw, groups, pad_mode,
-                    sum(seg_valid) if seg_valid else cin_g, split, acc_scale, table)
+                    sum(seg_valid) if seg_valid else cin_g, split, acc_scale, many_images, table)
 
 
 def _conv2d_params(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, act=None, act_param=0.0,
@@ -359,6 +360,7 @@ def _conv2d_params(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor
     P.act2 = ACT[act2]
     P.act_split = act_split
     P.acc_scale = spec.acc_scale
+    P.many_images = int(spec.many_images)
     P.act_param = act_param
     P.out_scale = out_scale
     P.epi = EPI[epi]
@@ -411,7 +413,8 @@ def conv2d(spec: ConvSpec, inputs: list[torch.Tensor], out: torch.Tensor, *, aux
         geo = spec.geometry_key
         if geo is None:
             geo = spec.geometry_key = (spec.cout, spec.kh, spec.kw, spec.sh, spec.sw, spec.ph, spec.pw, spec.dh, spec.dw, spec.groups,
-                                       spec.pad_mode, tuple(spec.seg_channels), spec.split, spec.acc_scale, tuple(spec.weight.shape))
+                                       spec.pad_mode, tuple(spec.seg_channels), spec.split, spec.acc_scale, spec.many_images,
+                                       tuple(spec.weight.shape))
         key = (geo, spec.weight.data_ptr(), None if spec.bias is None else spec.bias.data_ptr(),
                None if spec.weight_f32 is None else spec.weight_f32.data_ptr(), id(L), tuple(map(_tkey, inputs)), _tkey(out),
                _tkey(aux1), _tkey(aux2), _tkey(pre_add), tuple((k, tuple(v) if isinstance(v, list) else v) for k, v in kw.items()))

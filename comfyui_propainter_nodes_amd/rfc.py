@@ -47,12 +47,15 @@ class FlowCompleter:
         self.down = ops.make_conv_spec(wd.permute(0, 2, 3, 1).reshape(32, 75, 1, 1), p["downsample.0.bias"], self.dt,
                                        seg_channels=[self.down_kpad], seg_valid=[75], split=self.split).to(device)
         self.enc = [
-            (c2("encoder1.0.conv1.0", padding=1), ct("encoder1.0.conv2.0")),
-            (c2("encoder1.2.conv1.0", stride=2, padding=1), ct("encoder1.2.conv2.0")),
-            (c2("encoder2.0.conv1.0", padding=1), ct("encoder2.0.conv2.0")),
-            (c2("encoder2.2.conv1.0", stride=2, padding=1), ct("encoder2.2.conv2.0")),
+            (c2("encoder1.0.conv1.0", padding=1, many_images=True), ct("encoder1.0.conv2.0")),
+            (c2("encoder1.2.conv1.0", stride=2, padding=1, many_images=True), ct("encoder1.2.conv2.0")),
+            (c2("encoder2.0.conv1.0", padding=1, many_images=True), ct("encoder2.0.conv2.0")),
+            (c2("encoder2.2.conv1.0", stride=2, padding=1, many_images=True), ct("encoder2.2.conv2.0")),
         ]
-        self.mid = [c2(f"mid_dilation.{i}", padding=d, dilation=d) for i, d in ((0, 3), (2, 2), (4, 1))]
+        # r06 (ABI v12 `many_images`): the layers that see every image of the sub-video at once.  At 640x360 their 45 x 80 images and
+        # 36-chunk reductions look like the recurrences' one-time-step launches to a selection rule that never looks at the batch, and
+        # they ran on the split-K kernel at 224 TF/s (0.75 ms each, 3 ms per clip); with the hint: the halo tiles, ~800 TF/s
+        self.mid = [c2(f"mid_dilation.{i}", padding=d, dilation=d, many_images=True) for i, d in ((0, 3), (2, 2), (4, 1))]
         fp = "feat_prop_module."
         self.prop = {}
         for name, nseg in (("backward_", 2), ("forward_", 3)):
@@ -67,13 +70,13 @@ class FlowCompleter:
                 "bb0": c2(f"{fp}backbone.{name}.0", padding=1, seg_channels=[128] * nseg),
                 "bb2": c2(f"{fp}backbone.{name}.2", padding=1),
             }
-        self.fusion = c2(fp + "fusion", seg_channels=[128, 128])
-        self.dec2_0 = c2("decoder2.0", padding=1)
-        self.dec2_2 = c2("decoder2.2.conv", padding=1)
-        self.dec1_0 = c2("decoder1.0", padding=1)
-        self.dec1_2 = c2("decoder1.2.conv", padding=1)
-        self.up_0 = c2("upsample.0", padding=1)
-        self.up_2 = c2("upsample.2.conv", padding=1)
+        self.fusion = c2(fp + "fusion", seg_channels=[128, 128], many_images=True)
+        self.dec2_0 = c2("decoder2.0", padding=1, many_images=True)
+        self.dec2_2 = c2("decoder2.2.conv", padding=1, many_images=True)
+        self.dec1_0 = c2("decoder1.0", padding=1, many_images=True)
+        self.dec1_2 = c2("decoder1.2.conv", padding=1, many_images=True)
+        self.up_0 = c2("upsample.0", padding=1, many_images=True)
+        self.up_2 = c2("upsample.2.conv", padding=1, many_images=True)
 
     # ------------------------------------------------------------------------------------
     def _encode(self, x: torch.Tensor):

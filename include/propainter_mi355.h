@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 11
+#define PP_ABI_VERSION 12
 
 enum pp_dtype {
   PP_F32 = 0,
@@ -149,6 +149,12 @@ typedef struct {
   float acc_scale;   /* (ABI v9, PP_F32X2) the accumulators are multiplied by this before the bias is added; 0 = 1.  The packed
                         weights of a layer carry a power-of-two scale S (ops.split_pack_weight: max|w| S in [8192, 16384), so that
                         the LOW f16 term of every weight is a normal number) and acc_scale = 1 / S undoes it exactly */
+  int32_t many_images; /* (ABI v12) != 0: the caller states that this LAYER always runs on a batch of many images (flow completion's
+                          encoder / decoder layers over a whole sub-video: 2 (T - 1) images), so the kernel for small images with a
+                          long reduction (in-work-group split K, built for the ONE-time-step launches of the recurrences) is not
+                          considered.  Kernel selection otherwise never looks at the batch -- it decides on the pixels of one image,
+                          Cout and K, so that a rank of a sharded run and the single-GPU run sum every layer in the same order --
+                          and this flag keeps that property: it belongs to the layer, not to the launch.  0 = the r02-r06 rules */
 } pp_conv2d_params;
 
 int32_t pp_conv2d(void* stream, const pp_conv2d_params* p);

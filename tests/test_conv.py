@@ -245,6 +245,29 @@ def test_gemm_kernel_equals_flat_kernel(backend, cfg, pp_knobs):
         assert (outs[1].double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
 
 
+def test_many_images_hint_skips_the_split_k_kernel(backend, pp_knobs):
+    """ABI v12: a small-image / long-K layer (20 x 40 pixels, 36 chunks, 128 channels: the split-K kernel's territory) that its
+    caller marks `many_images` runs on the kernels PP_CONV_KSPLIT=0 would select -- bit for bit -- whatever the batch; without the
+    mark the split-K kernel sums in four K groups (close, not equal)."""
+    g = torch.Generator().manual_seed(71)
+    w = torch.randn(128, 128, 3, 3, generator=g) * 0.03
+    b = torch.randn(128, generator=g)
+    outs = {}
+    for n in (2, 5):
+        x = torch.randn(n, 20, 40, 128, generator=g).half().to(backend)
+        for name, hint, knobs in (("hint", True, {}), ("no ksplit", False, dict(PP_CONV_KSPLIT="0")), ("default", False, {})):
+            pp_knobs(PP_CONV_KSPLIT=knobs.get("PP_CONV_KSPLIT", "1"))
+            spec = ops.make_conv_spec(w, b, torch.float16, padding=2, dilation=2, many_images=hint).to(backend)
+            out = torch.full((n, 20, 40, 128), float("nan"), device=backend, dtype=torch.float16)
+            ops.conv2d(spec, [x], out, act="leaky", act_param=0.2)
+            outs[name] = out.cpu()
+        assert torch.equal(outs["hint"], outs["no ksplit"]), n
+        assert not torch.equal(outs["hint"], outs["default"]), "the unmarked layer should have taken the split-K kernel"
+        ref = F.leaky_relu(F.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.half().double(), b.double(), padding=2, dilation=2), 0.2)
+        for o in outs.values():
+            assert (o.double() - ref.permute(0, 2, 3, 1)).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_halo_c64_knob_is_bit_identical(emu_lib, pp_knobs):
     """r04: PP_CONV_HALO_C64=1 sends every 3x3 f16 compile-time-tap halo layer to the 64-channel tile (three work-groups per CU;
     the occupancy A/B of profiles/r04_conv_counters.md, default off until timed).  A tile shape changes which work-group computes

@@ -24,5 +24,5 @@ prof = ops.CONV_PROFILE.summary()
 ops.CONV_PROFILE = None
 tot = sum(v["ms"] for v in prof.values())
 print(f"total conv ms {tot:.1f}")
-for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:40]:
+for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:70]:
     print(f"{v['ms']:8.1f} ms  {v['n']:5d}x  {v['flops'] / v['ms'] / 1e9:7.1f} TF/s  {k}")
