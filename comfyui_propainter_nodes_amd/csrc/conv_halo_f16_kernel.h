@@ -445,7 +445,7 @@ static int launch_halo_f16_cfg(void* stream, const ConvK& k, int Z, HaloGeom g) 
 template <typename OT>
 static int launch_halo_f16_t(void* stream, const ConvK& k, int Z) {
   HaloGeom g;
-  if (!halo_geometry(k, Z, 320, &g)) return 1;
+  if (!halo_geometry(k, Z, 320, &g, 8, options().halo_min_cout)) return 1;
   const bool big = g.hrows > 192;  // dilated 3x3 (12 x 20, 14 x 22): five 64-row copy passes instead of three
   if (options().halo_ct && k.kh == 3 && k.kw == 3 && k.dh == 1 && k.dw == 1) {
     if (k.Cout > 64 && !options().halo_c64) {

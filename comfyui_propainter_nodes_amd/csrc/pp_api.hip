@@ -103,6 +103,8 @@ static void load_options() {
   if (const char* e = getenv("PP_CONV_EPI")) o.epi_lds = e[0] != 'd';
   o.epi_oct = 1;
   if (const char* e = getenv("PP_CONV_EPI_OCT")) o.epi_oct = e[0] != '0';
+  o.halo_min_cout = 33;
+  if (const char* e = getenv("PP_CONV_HALO_MINCOUT")) o.halo_min_cout = atoi(e) > 0 ? atoi(e) : 33;
   o.upsample_b4 = 1;
   if (const char* e = getenv("PP_UPSAMPLE_B4")) o.upsample_b4 = e[0] != '0';
   o.deform_xcd = 1;

@@ -24,6 +24,8 @@
 //                                through LDS into whole-cache-line rows (r05 default; bit-identical)
 //   PP_CONV_EPI_OCT  0           the GEMM kernel stores its f16 outputs as 8-byte quads (r01-r05) instead of pairing channel-adjacent quads
 //                                into 16-byte stores with v_permlane16_swap (r06 default; bit-identical)
+//   PP_CONV_HALO_MINCOUT n       f16 halo-tile kernels for layers with at least n output channels (default 33; the 17..32-channel layers
+//                                of flow completion's full-resolution decoder otherwise run on the flat 32-channel tiles)
 //   PP_UPSAMPLE_B4   0           pp_upsample2x with one thread per output pixel (r01-r05) instead of per 2 x 2 output block (bit-identical)
 //   PP_DEFORM_XCD    0           pp_deform_cols / pp_deform_conv walk their pixel blocks in launch order instead of XCD-contiguous order
 #pragma once
@@ -44,6 +46,7 @@ struct Options {
   int gemm_cfg;    // 0 auto, 1..5 pinned
   int epi_lds;     // 1 (default): LDS-transposed epilogue; 0: direct quads
   int epi_oct;     // 1 (default): GEMM kernel, f16 outputs: paired quads, 16-byte stores (r06); 0: 8-byte quads
+  int halo_min_cout;  // f16 halo-tile kernels from this many output channels on (default 33; r06 A/B: 17 = the 32-channel layers too)
   int upsample_b4; // 1 (default): pp_upsample2x computes 2 x 2 output blocks per thread (r06); 0: one output pixel per thread
   int deform_xcd;  // 1 (default): the deformable-sampling kernels walk their pixel blocks in XCD-contiguous order
 };
