@@ -16,14 +16,14 @@ corr = torch.randn(P, h, w, 352, device=dev)[..., :324]
 spec = ops.make_conv_spec(torch.randn(256, 324, 1, 1) * 0.05, torch.randn(256), torch.float32, split=True).to(dev)
 out = torch.empty(P, h, w, 256, device=dev)
 ref = None
-for tile in ("", "classic", "large", "small", "xlforce"):
+for tile in ("", "large", "", "large", "", "large", "xlforce", "classic"):
     if tile:
         os.environ["PP_CONV_TILE"] = tile
     else:
         os.environ.pop("PP_CONV_TILE", None)
     lib.reload_options()
     ops._PARAMS.clear()
-    for _ in range(3):
+    for _ in range(10):
         ops.conv2d(spec, [corr], out, act="relu")
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
