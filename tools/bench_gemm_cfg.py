@@ -10,9 +10,10 @@ from comfyui_propainter_nodes_amd import lib, ops  # noqa: E402
 
 lib.load()
 dev = torch.device("cuda:0")
-for name, M, K, Cout, residual in (("qkv", 30780, 512, 1536, False), ("proj + residual", 30780, 512, 512, True), ("fc1", 30780, 512, 1960, False),
+SHAPES = (("ss (materialised) K 6272", 17820, 6272, 512, False), ("kv pooled tokens", 1547, 512, 1024, False), ("qkv", 30780, 512, 1536, False))
+for name, M, K, Cout, residual in SHAPES + (("qkv", 30780, 512, 1536, False), ("proj + residual", 30780, 512, 512, True), ("fc1", 30780, 512, 1960, False),
                                    ("fc2 (materialised) + residual", 30780, 1960, 512, True), ("sc fc", 17820, 512, 6272, False),
-                                   ("dcn 1x1", 201600, 1152, 128, False), ("qkv 6-frame window", 9720, 512, 1536, False)):
+                                   ("dcn 1x1", 201600, 1152, 128, False), ("qkv 6-frame window", 9720, 512, 1536, False))[:0]:
     x = torch.randn(1, 1, M, K, device=dev).half()
     spec = ops.make_conv_spec(torch.randn(Cout, K, 1, 1) * 0.05, torch.randn(Cout), torch.float16).to(dev)
     res = torch.randn(1, 1, M, Cout, device=dev).half()
